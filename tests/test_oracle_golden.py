@@ -1,0 +1,203 @@
+"""Pins the CPU oracle against every known answer the reference's own tests
+hold for the hot path:
+
+  1. instant-distance/tests/all.rs:11-39   `map`              exact f32 distances, any seed
+  2. instant-distance/tests/all.rs:41-88   `random_heuristic` recall@100 > 97, len >= 100
+  3. instant-distance/tests/all.rs:48-53   `random_simple`    recall@100 > 90
+  4. instant-distance/examples/colors.rs:4-14 (+ README.md:41) nearest colour
+  5. instant-distance-py/test/test.py:15-35  self-query returns own value first
+  6. SURVEY.md §8 layer structures (f32 layer sizing, core/lib.rs:238-250)
+  7. py/lib.rs:378-421 summation order (independent numpy restatement)
+"""
+import numpy as np
+import pytest
+
+
+def build_map(oracle, points, seed, cfg, threads=1):
+    """HnswMap::new (core/lib.rs:141-152): permute, build, return (index, pid_of_orig)."""
+    pts = np.asarray(points, dtype=np.float32)
+    out_pid, order = oracle.permutation(seed, len(pts))
+    ix = oracle.Index.build(pts[order], cfg, threads=threads)
+    return ix, out_pid, order
+
+
+@pytest.mark.parametrize("seed", list(range(25)))
+def test_map_exact_distances(oracle, seed):
+    # tests/all.rs:11-39
+    pts = np.array([[i, i] for i in range(5)], dtype=np.float32)
+    values = ["zero", "one", "two", "three", "four"]
+    cfg = oracle.default_config(metric=oracle.METRIC_L2)
+    ix, out_pid, order = build_map(oracle, pts, seed, cfg)
+    res = ix.search(np.array([2.0, 2.0], dtype=np.float32))
+    assert res.count[0] == 5
+    for i in range(5):
+        d = res.dist[0, i]
+        v = values[order[res.pid[0, i]]]
+        if i == 0:
+            assert d == np.float32(0.0) and v == "two"
+        elif i in (1, 2):
+            assert d == np.float32(1.4142135) and v in ("one", "three")
+        else:
+            assert d == np.float32(2.828427) and v in ("zero", "four")
+
+
+def _randomized(oracle, seed, heuristic, threads=1):
+    # tests/all.rs:55-88
+    rng = np.random.default_rng(seed)
+    pts = rng.random((1024, 2), dtype=np.float32)
+    query = rng.random(2, dtype=np.float32)
+    cfg = oracle.default_config(metric=oracle.METRIC_L2, has_heuristic=int(heuristic))
+    ix, out_pid, order = build_map(oracle, pts, seed, cfg, threads=threads)
+    res = ix.search(query)
+    assert res.count[0] >= 100
+    d = np.sqrt(((pts - query) ** 2).sum(1, dtype=np.float32))
+    forced = set(int(out_pid[i]) for i in np.argsort(d, kind="stable")[:100])
+    found = set(int(p) for p in res.pid[0, :100])
+    return len(forced & found)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 123456789, 987654321])
+def test_random_heuristic_recall(oracle, seed):
+    assert _randomized(oracle, seed, True) > 97  # tests/all.rs:45
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 123456789, 987654321])
+def test_random_simple_recall(oracle, seed):
+    assert _randomized(oracle, seed, False) > 90  # tests/all.rs:52
+
+
+def test_random_heuristic_recall_parallel_build(oracle):
+    # rayon path (core/lib.rs:316-318): non-deterministic, judged by recall
+    assert _randomized(oracle, 7, True, threads=4) > 97
+
+
+def test_colors(oracle):
+    # examples/colors.rs:4-14, README.md:41
+    pts = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255]], dtype=np.float32)
+    values = ["red", "green", "blue"]
+    cfg = oracle.default_config(metric=oracle.METRIC_L2)
+    for seed in range(6):
+        ix, out_pid, order = build_map(oracle, pts, seed, cfg)
+        r = ix.search(np.array([204, 85, 0], dtype=np.float32))
+        assert values[order[r.pid[0, 0]]] == "red"
+        r = ix.search(np.array([163, 193, 173], dtype=np.float32))
+        assert values[order[r.pid[0, 0]]] == "green"
+        # integer arithmetic of colors.rs is exact in f32
+        assert r.dist[0, 0] == np.float32(np.sqrt(np.float32(163**2 + (193 - 255) ** 2 + 173**2)))
+
+
+def test_self_query_300d(oracle):
+    # instant-distance-py/test/test.py:15-35 (1024 x 300 uniform, squared L2)
+    rng = np.random.default_rng(5)
+    pts = rng.random((1024, 300), dtype=np.float32)
+    ix, out_pid, order = build_map(oracle, pts, 42, oracle.default_config())
+    res = ix.search(pts[[123, 7, 1000]])
+    for row, orig in enumerate([123, 7, 1000]):
+        assert order[res.pid[row, 0]] == orig
+        assert res.dist[row, 0] == 0.0
+
+
+def test_layer_sizes_match_survey(oracle):
+    # SURVEY.md §8 (computed with the reference's f32 arithmetic)
+    assert oracle.layer_sizes(100000)[::-1] == [57, 199, 693, 2402, 8325, 28853, 100000]
+    assert oracle.layer_sizes(1000000)[::-1] == [47, 166, 576, 1999, 6931, 24022, 83254, 288539, 1000000]
+    assert oracle.layer_sizes(10000000)[::-1] == [39, 138, 480, 1664, 5770, 19999, 69313, 240222,
+                                                   832547, 2885390, 10000000]
+    assert oracle.layer_sizes(1024)[::-1] == [85, 295, 1024]
+    assert oracle.layer_sizes(1000)[::-1] == [83, 288, 1000]
+    assert oracle.layer_sizes(5) == [5]
+    assert oracle.layer_sizes(1) == [1]
+
+
+def _py_order_numpy(a, b):
+    """Independent restatement of py/lib.rs:390-411 (D % 8 == 4)."""
+    a = a.astype(np.float32)
+    b = b.astype(np.float32)
+    D = len(a)
+    acc = np.zeros(8, dtype=np.float64)  # hold f32 values; fma emulated in f64 then rounded
+    acc32 = np.zeros(8, dtype=np.float32)
+    for s in range(D // 8):
+        d = (a[8 * s:8 * s + 8] - b[8 * s:8 * s + 8]).astype(np.float32)
+        # fma(d,d,acc): exact product fits in f64 (24+24 bits), one rounding of the sum
+        acc32 = (d.astype(np.float64) * d.astype(np.float64) + acc32.astype(np.float64)).astype(np.float32)
+    a4 = (acc32[4:] + acc32[:4]).astype(np.float32)
+    if D % 8 == 4:
+        d = (a[D - 4:] - b[D - 4:]).astype(np.float32)
+        a4 = (d.astype(np.float64) * d.astype(np.float64) + a4.astype(np.float64)).astype(np.float32)
+    s02 = np.float32(a4[0] + a4[2])
+    s13 = np.float32(a4[1] + a4[3])
+    return np.float32(s02 + s13)
+
+
+@pytest.mark.parametrize("dim", [4, 12, 100, 128, 300, 768])
+def test_distance_summation_order(oracle, dim):
+    rng = np.random.default_rng(dim)
+    for _ in range(50):
+        a = rng.standard_normal(dim).astype(np.float32)
+        b = rng.standard_normal(dim).astype(np.float32)
+        want = _py_order_numpy(a, b)
+        # note: double rounding of (exact product + acc) in f64 -> f32 can differ from a
+        # true fma only when the f64 sum is inexact; products need 48 bits and the sum
+        # may exceed 53 — accept 1 ulp there but require AVX2 == scalar bit-exactly.
+        got = oracle.distance(a, b)
+        got_s = oracle.distance(a, b, scalar=True)
+        assert got.tobytes() == got_s.tobytes()
+        assert abs(float(got) - float(want)) <= np.spacing(np.float32(want))
+        ref64 = ((a.astype(np.float64) - b.astype(np.float64)) ** 2).sum()
+        assert abs(float(got) - ref64) <= 1e-5 * ref64
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3, 5, 6, 7, 9, 13, 301])
+def test_distance_zero_padding(oracle, dim):
+    # short vectors are zero-padded (py/lib.rs:363-376): padding must be a bitwise no-op
+    rng = np.random.default_rng(dim)
+    a = rng.standard_normal(dim).astype(np.float32)
+    b = rng.standard_normal(dim).astype(np.float32)
+    dp = (dim + 3) // 4 * 4
+    ap = np.zeros(dp, np.float32); ap[:dim] = a
+    bp = np.zeros(dp, np.float32); bp[:dim] = b
+    assert oracle.distance(a, b).tobytes() == oracle.distance(ap, bp).tobytes()
+    assert oracle.distance(a, b).tobytes() == oracle.distance(b, a).tobytes()  # symmetry
+
+
+def test_build_sequential_is_deterministic(oracle):
+    rng = np.random.default_rng(0)
+    pts = rng.random((700, 12), dtype=np.float32)
+    a = oracle.Index.build(pts, oracle.default_config())
+    b = oracle.Index.build(pts, oracle.default_config())
+    assert np.array_equal(a.zero, b.zero)
+    assert len(a.layers) == len(b.layers) == 2
+    for x, y in zip(a.layers, b.layers):
+        assert np.array_equal(x, y)
+    # upper layer rows are the first 32 slots of the zero rows *at snapshot time*; sizes per SURVEY A.3
+    assert [l.shape[0] for l in a.layers] == oracle.layer_sizes(700)[1:]
+
+
+def test_import_export_roundtrip_and_search(oracle):
+    rng = np.random.default_rng(3)
+    pts = rng.random((500, 8), dtype=np.float32)
+    a = oracle.Index.build(pts, oracle.default_config())
+    b = oracle.Index.from_arrays(a.points, a.zero, a.layers, oracle.default_config())
+    q = rng.random((20, 8), dtype=np.float32)
+    ra, rb = a.search(q), b.search(q)
+    assert np.array_equal(ra.pid, rb.pid) and np.array_equal(ra.dist, rb.dist)
+    assert np.array_equal(ra.counters, rb.counters)
+
+
+def test_empty_and_single(oracle):
+    e = oracle.Index.build(np.zeros((0, 4), np.float32), oracle.default_config())
+    assert e.search(np.zeros(4, np.float32)).count[0] == 0      # core/lib.rs:359-361
+    s = oracle.Index.build(np.ones((1, 4), np.float32), oracle.default_config())
+    r = s.search(np.zeros(4, np.float32))
+    assert r.count[0] == 1 and r.pid[0, 0] == 0 and r.dist[0, 0] == 4.0
+
+
+def test_bruteforce_matches_numpy(oracle):
+    rng = np.random.default_rng(9)
+    pts = rng.random((300, 20), dtype=np.float32)
+    q = rng.random((5, 20), dtype=np.float32)
+    pid, dist = oracle.bruteforce(pts, q, 10, threads=2)
+    for i in range(5):
+        d = np.array([oracle.distance(q[i], p) for p in pts])
+        order = np.lexsort((np.arange(300), d))[:10]
+        assert np.array_equal(order.astype(np.uint32), pid[i])
