@@ -1,0 +1,193 @@
+/*
+ * idist.h — C ABI of libidist.so, the MI355X (gfx950) HNSW build+search engine
+ * that sits under instant-distance's Builder / Hnsw / HnswMap / Search / Point
+ * API (the drop-in boundary).
+ *
+ * The reference has NO FFI of its own: its boundary is the public Rust API.
+ * Each entry point below names the reference item it stands in for
+ * (paths relative to /root/reference/, core/ = instant-distance/src/).  The
+ * Rust-side binding a maintainer adds is shown in INTEGRATION.md and shipped as
+ * source in instant-distance_amd/rust-shim/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every host buffer, the
+ *     library owns all device memory behind the opaque handles;
+ *   - every call returns an idist_status (0 = ok); idist_last_error() gives a
+ *     thread-local message.  The reference API is infallible (it only panics at
+ *     core/lib.rs:256 and :148) so the shim `expect()`s these;
+ *   - points are handed over ALREADY IN PointId ORDER: the seed -> permutation
+ *     step (core/lib.rs:214,257-270, `rand` crate) stays on the caller's side;
+ *   - an idist_index is immutable after build/import and may be shared by any
+ *     number of threads; every idist_search_ctx owns its own stream + scratch
+ *     (the role of `&mut Search`, core/lib.rs:352-356).
+ *   - there is no CPU fallback: without a gfx950 device every compute entry
+ *     point fails with IDIST_ERR_NO_DEVICE.
+ */
+#ifndef IDIST_H
+#define IDIST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDIST_M 32u                 /* core/lib.rs:787 */
+#define IDIST_M2 64u                /* ZeroNode slots, core/types.rs:83-85 */
+#define IDIST_INVALID 0xFFFFFFFFu   /* PointId INVALID, core/types.rs:293 */
+#define IDIST_MAX_LAYERS 64u
+#define IDIST_MAX_EF 4096u
+
+typedef int32_t idist_status;
+enum {
+    IDIST_OK = 0,
+    IDIST_ERR_INVALID_ARG = 1,
+    IDIST_ERR_NO_DEVICE = 2,      /* no gfx950 GPU visible: there is no CPU path */
+    IDIST_ERR_HIP = 3,            /* HIP runtime error, see idist_last_error() */
+    IDIST_ERR_UNSUPPORTED = 4,    /* option the GPU engine does not implement (yet) */
+    IDIST_ERR_BAD_GRAPH = 5,      /* imported adjacency violates the reference's invariants */
+    IDIST_ERR_TIE_OVERFLOW = 6,   /* > IDIST tie capacity equidistant live candidates */
+    IDIST_ERR_INTERNAL = 7        /* device-side guard tripped */
+};
+
+enum {
+    IDIST_METRIC_L2SQ = 0, /* FloatArray::distance, instant-distance-py/src/lib.rs:378-421 */
+    IDIST_METRIC_L2 = 1    /* sqrt of it: tests/all.rs:93-97, examples/colors.rs:21-25 */
+};
+
+/* Builder fields, core/lib.rs:23-31 (defaults :101-128). */
+typedef struct idist_config {
+    uint32_t ef_search;         /* Builder::ef_search, default 100 */
+    uint32_t ef_construction;   /* Builder::ef_construction, default 100 */
+    float ml;                   /* Builder::ml, default 1/ln(32) */
+    int32_t has_heuristic;      /* Builder::select_heuristic(Some/None), default Some */
+    int32_t extend_candidates;  /* Heuristic::extend_candidates, default false */
+    int32_t keep_pruned;        /* Heuristic::keep_pruned, default true */
+    int32_t metric;             /* IDIST_METRIC_* (the Point::distance the caller would supply) */
+    uint32_t max_batch;         /* build scheduling: 1 = strictly sequential insertion (the
+                                   deterministic contract = reference with one rayon thread);
+                                   0 = library default; k = at most k concurrent inserts per
+                                   step (the rayon for_each of core/lib.rs:316-318). */
+} idist_config;
+
+typedef struct idist_index idist_index;
+typedef struct idist_search_ctx idist_search_ctx;
+
+typedef struct idist_index_info {
+    uint32_t n, dim;
+    uint32_t row_stride;        /* floats per stored row (blocked layout) */
+    uint32_t n_upper;           /* Hnsw.layers.len() */
+    uint32_t ef_search;
+    int32_t metric;
+    int32_t device;
+    uint32_t layer_len[IDIST_MAX_LAYERS]; /* layer_len[l-1] = rows of layers[l-1], l = 1..n_upper */
+} idist_index_info;
+
+/* Raw device views (for RCCL replication by the host: torch.distributed / ncclBroadcast). */
+typedef struct idist_device_buffers {
+    void* points;  size_t points_bytes;  /* f32 [n][row_stride], blocked layout */
+    void* zero;    size_t zero_bytes;    /* u32 [n][64] */
+    void* upper;   size_t upper_bytes;   /* u32 [sum layer_len][32], layer 1 first */
+} idist_device_buffers;
+
+/* Work counters that define the algorithmic bytes. */
+typedef struct idist_build_stats {
+    uint64_t n_dist;        /* descent distance evaluations (Search::push past `visited`) */
+    uint64_t n_exp0;        /* zero-array expansions */
+    uint64_t n_expU;        /* snapshot (UpperNode) expansions */
+    uint64_t n_heur_dist;   /* pairwise distances inside select_heuristic + neighbour re-selection */
+    uint64_t n_heur_rows;   /* candidate rows staged for select_heuristic */
+    uint64_t n_updates;     /* neighbour rows rewritten (ZeroNode::rewrite) */
+    uint64_t n_batches;
+    double seconds;         /* device time of the whole build (HIP events) */
+} idist_build_stats;
+
+/* ---- library ------------------------------------------------------------ */
+const char* idist_last_error(void);
+const char* idist_version(void);
+idist_status idist_device_count(int32_t* out);
+/* Builder::default(), core/lib.rs:101-113 (seed stays with the caller). */
+idist_status idist_default_config(idist_config* cfg);
+/* Layer sizing of Hnsw::new, core/lib.rs:238-250 (f32 multiply + truncation).
+ * cum[l] = nodes present on layer l, cum[0] = n; returns the layer count in *n_layers. */
+idist_status idist_layer_sizes(uint32_t n, float ml, uint32_t* cum, uint32_t cap, uint32_t* n_layers);
+
+/* Host helper (no GPU): the shuffle of Hnsw::new, core/lib.rs:214,257-270 — keys drawn with
+ * SmallRng::seed_from_u64(seed).random_range(0..n), sort_unstable by (key, index).
+ * out_pid[orig] = PointId, order[pid] = original index (either may be NULL).
+ * PARITY UNPINNED: the `rand` crate is not part of /root/reference (Cargo.lock is git-ignored);
+ * this restates xoshiro256++ / SplitMix64 seeding / widening-multiply range sampling.  A Rust
+ * caller keeps using the real crate and passes points in PointId order. */
+idist_status idist_permutation(uint64_t seed, uint32_t n, uint32_t* out_pid, uint32_t* order);
+
+/* ---- index -------------------------------------------------------------- */
+/* Builder::build_hnsw / Hnsw::new, core/lib.rs:83-85, 209-345 (after the permutation):
+ * inserts points 1..n per layer range (Construction::insert, :437-528, select_heuristic
+ * :636-698) on the GPU.  `points` is host memory, row-major n x dim, PointId order. */
+idist_status idist_index_build(const float* points, uint32_t n, uint32_t dim,
+                               const idist_config* cfg, int32_t device, idist_index** out);
+/* Same, points already resident on `device` (row-major n x dim f32). */
+idist_status idist_index_build_device(const void* d_points, uint32_t n, uint32_t dim,
+                                      const idist_config* cfg, int32_t device, idist_index** out);
+idist_status idist_index_build_stats(const idist_index* idx, idist_build_stats* out);
+
+/* Adopt an existing graph: the fields of `struct Hnsw`, core/lib.rs:194-199
+ * (points, zero: Vec<ZeroNode>, layers: Vec<Vec<UpperNode>>).  Rows are validated
+ * against the reference's invariants (ids < n, no duplicate before the first INVALID). */
+idist_status idist_index_import(const float* points, uint32_t n, uint32_t dim,
+                                const idist_config* cfg, const uint32_t* zero,
+                                const uint32_t* const* layers, const uint32_t* layer_len,
+                                uint32_t n_upper, int32_t device, idist_index** out);
+/* Empty index with the layer structure `layer_len` (replication target). */
+idist_status idist_index_alloc(uint32_t n, uint32_t dim, const idist_config* cfg,
+                               const uint32_t* layer_len, uint32_t n_upper, int32_t device,
+                               idist_index** out);
+/* Copy the graph back to host: zero must hold n*64, layers[l-1] layer_len[l-1]*32 u32. */
+idist_status idist_index_export(const idist_index* idx, uint32_t* zero, uint32_t* const* layers);
+idist_status idist_index_get_info(const idist_index* idx, idist_index_info* out);
+idist_status idist_index_device_buffers(const idist_index* idx, idist_device_buffers* out);
+/* Hnsw.ef_search is a field of the index (core/lib.rs:195); bench sweeps change it. */
+idist_status idist_index_set_ef_search(idist_index* idx, uint32_t ef_search);
+void idist_index_free(idist_index* idx);
+
+/* ---- search ------------------------------------------------------------- */
+/* Search::default(), core/lib.rs:767-778: reusable scratch (visited set, W, candidates)
+ * for up to `slots` queries in flight (0 = fill the chip). */
+idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_search_ctx** out);
+void idist_search_ctx_free(idist_search_ctx* ctx);
+
+/* Hnsw::search, core/lib.rs:352-383, for nq queries at once (nq == 1 backs the scalar
+ * call).  Results are Search.nearest: <= ef_search (pid, distance) pairs, nearest first
+ * (the caller's `.take(k)` is a prefix).  out_pid/out_dist: nq*ef_search, padded with
+ * IDIST_INVALID / +inf; out_count: nq; out_counters (optional): nq*3
+ * {n_dist, n_exp0, n_expU} per query.  Host pointers; blocks until done. */
+idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx,
+                                const float* queries, uint32_t nq, uint32_t* out_pid,
+                                float* out_dist, uint32_t* out_count, uint32_t* out_counters);
+/* Same with every pointer in device memory, enqueued on `hip_stream` (a hipStream_t, may
+ * be NULL) without synchronising: inputs/outputs stay resident in HBM. */
+idist_status idist_search_batch_device(const idist_index* idx, idist_search_ctx* ctx,
+                                       const void* d_queries, uint32_t nq, void* d_out_pid,
+                                       void* d_out_dist, void* d_out_count, void* d_out_counters,
+                                       void* hip_stream);
+/* Device-side status of the last launches on ctx (after the stream is synchronised). */
+idist_status idist_search_ctx_status(idist_search_ctx* ctx);
+/* HIP-event duration of the last search kernel launched through ctx, milliseconds. */
+idist_status idist_search_ctx_last_kernel_ms(idist_search_ctx* ctx, float* ms);
+
+/* Point::distance for id lists (core/lib.rs:780-782 as used at :709-710): out[q][i] =
+ * distance(queries[q], points[ids[q][i]]) for i < n_ids; IDIST_INVALID ids give +inf.
+ * Host pointers. The batched gather-L2 kernel on its own. */
+idist_status idist_distance_batch(const idist_index* idx, const float* queries, uint32_t nq,
+                                  const uint32_t* ids, uint32_t n_ids, float* out_dist);
+
+/* Exact k nearest neighbours by exhaustive scan with the canonical distance (the
+ * brute-force check of tests/all.rs:60-67); host pointers. */
+idist_status idist_bruteforce(const idist_index* idx, const float* queries, uint32_t nq,
+                              uint32_t k, uint32_t* out_pid, float* out_dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDIST_H */

@@ -1,0 +1,383 @@
+"""Host-side mirror of instant-distance's public API over the MI355X engine.
+
+Same names, argument meaning and error behaviour as the reference
+(/root/reference/instant-distance/src/lib.rs; Python flavour follows
+/root/reference/instant-distance-py/src/lib.rs):
+
+    Builder  (core/lib.rs:23-113)     Heuristic (core/lib.rs:115-128)
+    Hnsw     (core/lib.rs:194-397)    HnswMap   (core/lib.rs:131-173)
+    Search   (core/lib.rs:560-574)    Item / MapItem (core/lib.rs:399-413, 175-191)
+    PointId  (core/types.rs:241-253)  -> plain int (u32)
+
+`Point::distance` (core/lib.rs:780-782) is arbitrary user code in the reference and
+cannot run on a GPU; here a point is an f32 vector and the distance is one of the two
+the reference itself ships: squared L2 (FloatArray, the default) or L2 with sqrt
+(the Point of tests/all.rs and examples/colors.rs) — `Builder.metric()`.
+
+All compute goes through the C ABI (include/idist.h); there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import secrets
+from dataclasses import dataclass
+from typing import Any, Iterator, Sequence
+
+import numpy as np
+
+from . import _capi
+from ._capi import INVALID, M, M2, METRIC_L2, METRIC_L2SQ
+
+PointId = int
+
+
+def _lib():
+    return _capi.lib()
+
+
+@dataclass
+class Heuristic:
+    """core/lib.rs:115-128"""
+    extend_candidates: bool = False
+    keep_pruned: bool = True
+
+
+class Builder:
+    """Parameters for building the `Hnsw` (core/lib.rs:23-113)."""
+
+    def __init__(self):
+        c = _lib().default_config()
+        self._ef_search = int(c.ef_search)              # core/lib.rs:104
+        self._ef_construction = int(c.ef_construction)  # :105
+        self._heuristic: Heuristic | None = Heuristic() # :106
+        self._ml = float(c.ml)                          # :107
+        self._seed = secrets.randbits(64)               # :108 rand::random()
+        self._metric = METRIC_L2SQ
+        self._max_batch = 0
+        self._device = 0
+
+    @classmethod
+    def default(cls) -> "Builder":
+        return cls()
+
+    # -- reference setters (core/lib.rs:35-68) --
+    def ef_construction(self, ef_construction: int) -> "Builder":
+        self._ef_construction = int(ef_construction)
+        return self
+
+    def ef_search(self, ef: int) -> "Builder":
+        self._ef_search = int(ef)      # does NOT touch ef_construction (code, not the doc comment)
+        return self
+
+    def select_heuristic(self, params: Heuristic | None) -> "Builder":
+        self._heuristic = params
+        return self
+
+    def ml(self, ml: float) -> "Builder":
+        self._ml = float(np.float32(ml))
+        return self
+
+    def seed(self, seed: int) -> "Builder":
+        self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        return self
+
+    # -- additions of this engine --
+    def metric(self, metric: int) -> "Builder":
+        """METRIC_L2SQ (FloatArray, py/lib.rs:378-421) or METRIC_L2 (tests/all.rs:93-97)."""
+        self._metric = int(metric)
+        return self
+
+    def max_batch(self, k: int) -> "Builder":
+        """1 = strictly sequential insertion (deterministic contract); 0 = default."""
+        self._max_batch = int(k)
+        return self
+
+    def device(self, device: int) -> "Builder":
+        self._device = int(device)
+        return self
+
+    def into_parts(self):
+        """core/lib.rs:87-98"""
+        return (self._ef_search, self._ef_construction, self._ml, self._seed)
+
+    def _config(self) -> _capi.Config:
+        c = _lib().default_config()
+        c.ef_search = self._ef_search
+        c.ef_construction = self._ef_construction
+        c.ml = self._ml
+        c.has_heuristic = 0 if self._heuristic is None else 1
+        c.extend_candidates = int(bool(self._heuristic and self._heuristic.extend_candidates))
+        c.keep_pruned = int(bool(self._heuristic.keep_pruned)) if self._heuristic else 1
+        c.metric = self._metric
+        c.max_batch = self._max_batch
+        return c
+
+    def build(self, points, values: Sequence[Any]) -> "HnswMap":
+        """Builder::build (core/lib.rs:78-80)."""
+        return HnswMap._new(points, values, self)
+
+    def build_hnsw(self, points) -> tuple["Hnsw", list[PointId]]:
+        """Builder::build_hnsw (core/lib.rs:83-85): (index, original index -> PointId)."""
+        return Hnsw._new(points, self)
+
+
+class Search:
+    """Reusable search scratch, `Search::default()` (core/lib.rs:560-574, 767-778).
+
+    After `Hnsw.search(point, search)` it holds that query's results and is an
+    iterator over them like the binding's Search (py/lib.rs:177-208)."""
+
+    def __init__(self, slots: int = 0):
+        self._slots = slots
+        self._ctx = None
+        self._owner = None
+        self._items: list = []
+        self._cur = 0
+
+    def _bind(self, hnsw: "Hnsw"):
+        if self._owner is not hnsw:
+            self._release()
+            ctx = C.c_void_p()
+            _lib().check(_lib().idist_search_ctx_new(hnsw._h, self._slots, C.byref(ctx)))
+            self._ctx = ctx
+            self._owner = hnsw
+        return self._ctx
+
+    def _release(self):
+        if self._ctx is not None:
+            _lib().idist_search_ctx_free(self._ctx)
+            self._ctx = None
+            self._owner = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._cur >= len(self._items):
+            raise StopIteration
+        it = self._items[self._cur]
+        self._cur += 1
+        return it
+
+    def __len__(self):
+        return len(self._items)
+
+
+@dataclass
+class Item:
+    """core/lib.rs:399-413"""
+    distance: float
+    pid: PointId
+    point: np.ndarray
+
+
+@dataclass
+class MapItem:
+    """core/lib.rs:175-191"""
+    distance: float
+    pid: PointId
+    point: np.ndarray
+    value: Any
+
+
+@dataclass
+class BatchResult:
+    pid: np.ndarray       # [nq, ef_search] uint32, INVALID padded
+    distance: np.ndarray  # [nq, ef_search] float32, +inf padded
+    count: np.ndarray     # [nq]
+    counters: np.ndarray | None  # [nq, 3] {n_dist, n_exp0, n_expU}
+
+
+def _as_points(points) -> np.ndarray:
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    if pts.ndim == 1:
+        pts = pts.reshape(0, 1) if pts.size == 0 else pts.reshape(1, -1)
+    if pts.ndim != 2:
+        raise TypeError("points must be an [n, dim] array of f32")
+    return pts
+
+
+class Hnsw:
+    """core/lib.rs:194-397.  Owns the points in PointId order and the device index."""
+
+    def __init__(self, handle, points: np.ndarray, ef_search: int):
+        self._h = handle
+        self.points = points          # [n, dim] in PointId order (Index<PointId>, core/types.rs:269-275)
+        self._ef_search = ef_search
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None:
+                _lib().idist_index_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def builder() -> Builder:
+        return Builder()
+
+    # -- construction --
+    @classmethod
+    def _new(cls, points, builder: Builder) -> tuple["Hnsw", list[PointId]]:
+        """Hnsw::new (core/lib.rs:209-345): shuffle on the host, build on the GPU."""
+        pts = _as_points(points)
+        n, dim = pts.shape
+        L = _lib()
+        out_pid = np.zeros(max(n, 1), dtype=np.uint32)
+        order = np.zeros(max(n, 1), dtype=np.uint32)
+        L.check(L.idist_permutation(C.c_uint64(builder._seed), n, _capi.u32p(out_pid), _capi.u32p(order)))
+        ordered = np.ascontiguousarray(pts[order[:n]]) if n else pts.reshape(0, max(dim, 1))
+        h = cls.from_ordered_points(ordered, builder)
+        return h, [int(x) for x in out_pid[:n]]
+
+    @classmethod
+    def from_ordered_points(cls, points_in_pid_order, builder: Builder | None = None) -> "Hnsw":
+        """Build from points that already are in PointId order (no shuffle)."""
+        builder = builder or Builder()
+        pts = _as_points(points_in_pid_order)
+        n, dim = pts.shape
+        cfg = builder._config()
+        h = C.c_void_p()
+        L = _lib()
+        L.check(L.idist_index_build(_capi.f32p(pts), n, max(dim, 1), C.byref(cfg), builder._device, C.byref(h)))
+        return cls(h, pts, builder._ef_search)
+
+    @classmethod
+    def from_parts(cls, points_in_pid_order, zero, layers, builder: Builder | None = None) -> "Hnsw":
+        """Adopt the fields of `struct Hnsw` (core/lib.rs:194-199): points, zero, layers."""
+        builder = builder or Builder()
+        pts = _as_points(points_in_pid_order)
+        n, dim = pts.shape
+        zero = np.ascontiguousarray(zero, dtype=np.uint32).reshape(n, M2)
+        layers = [np.ascontiguousarray(l, dtype=np.uint32).reshape(-1, M) for l in layers]
+        ptrs = (C.POINTER(C.c_uint32) * max(len(layers), 1))(*[_capi.u32p(l) for l in layers])
+        lens = np.array([l.shape[0] for l in layers] + [0], dtype=np.uint32)
+        cfg = builder._config()
+        h = C.c_void_p()
+        L = _lib()
+        L.check(L.idist_index_import(_capi.f32p(pts), n, max(dim, 1), C.byref(cfg), _capi.u32p(zero), ptrs,
+                                     _capi.u32p(lens), len(layers), builder._device, C.byref(h)))
+        return cls(h, pts, builder._ef_search)
+
+    # -- introspection --
+    def info(self) -> _capi.IndexInfo:
+        info = _capi.IndexInfo()
+        _lib().check(_lib().idist_index_get_info(self._h, C.byref(info)))
+        return info
+
+    def into_parts(self):
+        """(zero [n,64], layers [[len,32], ...]) copied back from the device."""
+        info = self.info()
+        zero = np.zeros((info.n, M2), dtype=np.uint32)
+        layers = [np.zeros((info.layer_len[l], M), dtype=np.uint32) for l in range(info.n_upper)]
+        ptrs = (C.POINTER(C.c_uint32) * max(len(layers), 1))(*[_capi.u32p(l) for l in layers])
+        _lib().check(_lib().idist_index_export(self._h, _capi.u32p(zero), ptrs))
+        return zero, layers
+
+    def build_stats(self) -> _capi.BuildStats:
+        st = _capi.BuildStats()
+        _lib().check(_lib().idist_index_build_stats(self._h, C.byref(st)))
+        return st
+
+    def set_ef_search(self, ef: int):
+        _lib().check(_lib().idist_index_set_ef_search(self._h, int(ef)))
+        self._ef_search = int(ef)
+
+    def __len__(self):
+        return self.points.shape[0]
+
+    def __getitem__(self, pid: PointId) -> np.ndarray:
+        return self.points[pid]
+
+    def iter(self) -> Iterator[tuple[PointId, np.ndarray]]:
+        """core/lib.rs:386-391"""
+        return ((i, p) for i, p in enumerate(self.points))
+
+    # -- search --
+    def search_batch(self, queries, search: Search, counters: bool = False) -> BatchResult:
+        """Hnsw::search (core/lib.rs:352-383) for many queries in one launch."""
+        q = _as_points(queries)
+        if q.shape[0] and self.points.shape[0] and q.shape[1] != self.points.shape[1]:
+            raise TypeError(f"query dim {q.shape[1]} != index dim {self.points.shape[1]}")
+        nq = q.shape[0]
+        ef = self._ef_search
+        pid = np.full((nq, ef), INVALID, dtype=np.uint32)
+        dist = np.full((nq, ef), np.inf, dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        ctr = np.zeros((nq, 3), dtype=np.uint32) if counters else None
+        if nq:
+            ctx = search._bind(self)
+            L = _lib()
+            L.check(L.idist_search_batch(self._h, ctx, _capi.f32p(q), nq, _capi.u32p(pid), _capi.f32p(dist),
+                                         _capi.u32p(cnt), _capi.u32p(ctr) if counters else None))
+        return BatchResult(pid, dist, cnt, ctr)
+
+    def search(self, point, search: Search) -> Search:
+        """Search the index for the points nearest to `point` (core/lib.rs:352-383).
+
+        Returns `search`, now an iterator over <= ef_search `Item`s, nearest first."""
+        r = self.search_batch(np.asarray(point, dtype=np.float32).reshape(1, -1), search)
+        c = int(r.count[0])
+        search._items = [Item(float(r.distance[0, i]), int(r.pid[0, i]), self.points[int(r.pid[0, i])]) for i in range(c)]
+        search._cur = 0
+        return search
+
+    def get(self, i: int, search: Search) -> Item | None:
+        """core/lib.rs:393-396"""
+        return search._items[i] if 0 <= i < len(search._items) else None
+
+    def distances(self, queries, ids) -> np.ndarray:
+        """Point::distance over id lists (the gather-L2 kernel on its own)."""
+        q = _as_points(queries)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32).reshape(q.shape[0], -1)
+        out = np.zeros(ids.shape, dtype=np.float32)
+        L = _lib()
+        L.check(L.idist_distance_batch(self._h, _capi.f32p(q), q.shape[0], _capi.u32p(ids), ids.shape[1], _capi.f32p(out)))
+        return out
+
+    def bruteforce(self, queries, k: int):
+        """Exact k-NN by exhaustive scan (the check in tests/all.rs:60-67)."""
+        q = _as_points(queries)
+        pid = np.zeros((q.shape[0], k), dtype=np.uint32)
+        dist = np.zeros((q.shape[0], k), dtype=np.float32)
+        L = _lib()
+        L.check(L.idist_bruteforce(self._h, _capi.f32p(q), q.shape[0], k, _capi.u32p(pid), _capi.f32p(dist)))
+        return pid, dist
+
+
+class HnswMap:
+    """core/lib.rs:131-173"""
+
+    def __init__(self, hnsw: Hnsw, values: list):
+        self.hnsw = hnsw
+        self.values = values
+
+    @classmethod
+    def _new(cls, points, values: Sequence[Any], builder: Builder) -> "HnswMap":
+        hnsw, ids = Hnsw._new(points, builder)
+        # values re-ordered by PointId (core/lib.rs:144-149); too few values is a panic there (:148)
+        if len(values) < len(ids):
+            raise IndexError("values.len() < points.len() (core/lib.rs:148 panics)")
+        new = [None] * len(ids)
+        for src, pid in enumerate(ids):
+            new[pid] = values[src]
+        return cls(hnsw, new)
+
+    def search(self, point, search: Search) -> Search:
+        """core/lib.rs:154-162"""
+        self.hnsw.search(point, search)
+        search._items = [MapItem(it.distance, it.pid, it.point, self.values[it.pid]) for it in search._items]
+        return search
+
+    def iter(self):
+        return self.hnsw.iter()
+
+    def get(self, i: int, search: Search):
+        return search._items[i] if 0 <= i < len(search._items) else None

@@ -1,0 +1,854 @@
+// idist_capi.hip — C ABI (include/idist.h) over the gfx950 kernels.
+// Host side only orchestrates: allocation, layout conversion, launch schedule
+// of the build (Hnsw::new, core/lib.rs:209-345) and of the batched search.
+#include "../../include/idist.h"
+#include "idist_kernels.hpp"
+
+#ifndef IDIST_EMU
+#include <hip/hip_runtime.h>
+#define IDIST_LAUNCH(kfn, grid, block, smem, stream, ...) kfn<<<(grid), (block), (smem), (stream)>>>(__VA_ARGS__)
+#else
+#define IDIST_LAUNCH(kfn, grid, block, smem, stream, ...) \
+    ::emu::launch((grid), (block), (smem), [=]() { kfn(__VA_ARGS__); })
+#endif
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace idist;
+
+namespace {
+
+thread_local std::string g_err;
+
+idist_status fail(idist_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(IDIST_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                        __LINE__);                                                                     \
+    } while (0)
+
+#define CHK(expr)                        \
+    do {                                 \
+        idist_status _s = (expr);        \
+        if (_s != IDIST_OK) return _s;   \
+    } while (0)
+
+struct Layout {
+    uint32_t stride, nb, rs, tail;
+};
+Layout make_layout(uint32_t dim) {
+    const uint32_t dp = (dim + 3u) & ~3u;      // zero padding is a bitwise no-op (fma(0,0,acc) == acc)
+    const uint32_t steps = dp / 8u;            // chunks_exact(8), instant-distance-py/src/lib.rs:391
+    Layout L;
+    L.tail = (dp % 8u) == 4u ? 1u : 0u;        // :402-405
+    L.nb = steps / 4u;
+    L.rs = steps % 4u;
+    const uint32_t used = 32u * L.nb + 8u * L.rs + 4u * L.tail;
+    L.stride = std::max(16u, (used + 15u) & ~15u);
+    return L;
+}
+
+// Layer sizing of Hnsw::new, core/lib.rs:238-250 (f32 multiply + truncation, `as usize` saturates)
+uint32_t layer_sizes(uint32_t n, float ml, uint32_t* cum, uint32_t cap) {
+    uint32_t cnt = 0;
+    size_t num = n;
+    for (;;) {
+        volatile float prod = (float)num * ml;
+        size_t next;
+        if (!(prod > 0.0f)) next = 0;
+        else if (prod >= 18446744073709551616.0f) next = (size_t)-1;
+        else next = (size_t)prod;
+        if (next < IDIST_M) break;
+        if (cnt + 1 >= cap) return 0;  // too many layers
+        cum[cnt++] = (uint32_t)num;
+        num = next;
+    }
+    cum[cnt++] = (uint32_t)num;
+    return cnt;
+}
+
+idist_status check_device(int32_t device) {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return fail(IDIST_ERR_NO_DEVICE, "no HIP device visible (%s); libidist has no CPU path",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= cnt) return fail(IDIST_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, cnt);
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return fail(IDIST_ERR_NO_DEVICE, "device %d is %s; libidist is built for gfx950 (MI355X) only", device,
+                    p.gcnArchName);
+    HIPCHK(hipSetDevice(device));
+    return IDIST_OK;
+}
+
+idist_status validate_config(const idist_config* cfg, bool for_build) {
+    if (!cfg) return fail(IDIST_ERR_INVALID_ARG, "config is null");
+    if (cfg->ef_search > IDIST_MAX_EF) return fail(IDIST_ERR_INVALID_ARG, "ef_search %u > %u", cfg->ef_search, IDIST_MAX_EF);
+    if (cfg->metric != IDIST_METRIC_L2SQ && cfg->metric != IDIST_METRIC_L2)
+        return fail(IDIST_ERR_INVALID_ARG, "unknown metric %d", cfg->metric);
+    if (for_build) {
+        if (cfg->ef_construction == 0 || cfg->ef_construction > IDIST_MAX_EF)
+            return fail(IDIST_ERR_INVALID_ARG, "ef_construction %u out of [1,%u]", cfg->ef_construction, IDIST_MAX_EF);
+        if (!cfg->has_heuristic)
+            return fail(IDIST_ERR_UNSUPPORTED,
+                        "select_heuristic(None) (core/lib.rs:466-469,497-515) is not implemented on the GPU engine");
+        if (cfg->extend_candidates)
+            return fail(IDIST_ERR_UNSUPPORTED,
+                        "Heuristic::extend_candidates=true is not implemented (it deadlocks in the reference: "
+                        "core/lib.rs:649 read-locks a node write-locked at :438)");
+    }
+    return IDIST_OK;
+}
+
+}  // namespace
+
+struct idist_index {
+    int32_t device = 0;
+    idist_config cfg{};
+    uint32_t n = 0, dim = 0;
+    Layout L{};
+    uint32_t n_upper = 0;
+    uint32_t layer_len[IDIST_MAX_LAYERS] = {0};
+    uint64_t layer_off[IDIST_MAX_LAYERS] = {0};
+    size_t upper_rows = 0;
+    float* d_points = nullptr;
+    uint32_t* d_zero = nullptr;
+    uint32_t* d_upper = nullptr;
+    uint64_t* d_layer_off = nullptr;
+    int n_cu = 256;
+    idist_build_stats stats{};
+
+    IndexView view() const {
+        IndexView v;
+        v.points = d_points;
+        v.zero = d_zero;
+        v.upper = d_upper;
+        v.layer_off = d_layer_off;
+        v.n = n;
+        v.dim = dim;
+        v.stride = L.stride;
+        v.nb = L.nb;
+        v.rs = L.rs;
+        v.tail = L.tail;
+        v.n_upper = n_upper;
+        v.metric = (uint32_t)cfg.metric;
+        return v;
+    }
+};
+
+struct idist_search_ctx {
+    const idist_index* idx = nullptr;
+    uint32_t slots = 0;
+    size_t vis_stride = 0;
+    uint8_t* d_visited = nullptr;
+    uint8_t* d_gen = nullptr;
+    uint32_t* d_next = nullptr;    // [0] queue head, [1] status
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // staging for the host-pointer API
+    float* d_q = nullptr;
+    uint32_t* d_pid = nullptr;
+    float* d_dist = nullptr;
+    uint32_t* d_cnt = nullptr;
+    uint32_t* d_ctr = nullptr;
+    size_t cap_q = 0, cap_out = 0, cap_nq = 0;
+};
+
+namespace {
+
+#define IDIST_DISPATCH(L, CALL)                                         \
+    do {                                                                \
+        if ((L).nb == 4 && (L).rs == 0 && (L).tail == 0) { CALL(4, 0, 0); }        /* dim 128 */ \
+        else if ((L).nb == 9 && (L).rs == 1 && (L).tail == 1) { CALL(9, 1, 1); }   /* dim 300 */ \
+        else if ((L).nb == 24 && (L).rs == 0 && (L).tail == 0) { CALL(24, 0, 0); } /* dim 768 */ \
+        else { CALL(-1, -1, -1); }                                      \
+    } while (0)
+
+idist_status index_alloc(uint32_t n, uint32_t dim, const idist_config* cfg, const uint32_t* layer_len,
+                         uint32_t n_upper, int32_t device, idist_index** out) {
+    if (!out) return fail(IDIST_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (dim == 0 || dim > 65536) return fail(IDIST_ERR_INVALID_ARG, "dim %u out of [1,65536]", dim);
+    if (n == 0xFFFFFFFFu) return fail(IDIST_ERR_INVALID_ARG, "n must be < u32::MAX (core/lib.rs:256)");
+    if (n_upper >= IDIST_MAX_LAYERS) return fail(IDIST_ERR_INVALID_ARG, "more than %u layers", IDIST_MAX_LAYERS);
+    CHK(check_device(device));
+    idist_index* ix = new idist_index();
+    ix->device = device;
+    ix->cfg = *cfg;
+    ix->n = n;
+    ix->dim = dim;
+    ix->L = make_layout(dim);
+    ix->n_upper = n_upper;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess) ix->n_cu = p.multiProcessorCount;
+    size_t rows = 0;
+    for (uint32_t l = 0; l < n_upper; l++) {
+        if (layer_len[l] > n) { delete ix; return fail(IDIST_ERR_INVALID_ARG, "layer_len[%u] = %u > n", l, layer_len[l]); }
+        ix->layer_len[l] = layer_len[l];
+        ix->layer_off[l] = rows;
+        rows += layer_len[l];
+    }
+    ix->upper_rows = rows;
+    auto cleanup = [&](idist_status s) { idist_index_free(ix); return s; };
+    auto alloc = [&](void** p, size_t bytes) -> idist_status {
+        HIPCHK(hipMalloc(p, std::max<size_t>(bytes, 256)));
+        return IDIST_OK;
+    };
+    idist_status s;
+    if ((s = alloc((void**)&ix->d_points, (size_t)n * ix->L.stride * 4)) != IDIST_OK) return cleanup(s);
+    if ((s = alloc((void**)&ix->d_zero, (size_t)n * IDIST_M2 * 4)) != IDIST_OK) return cleanup(s);
+    if ((s = alloc((void**)&ix->d_upper, rows * IDIST_M * 4)) != IDIST_OK) return cleanup(s);
+    if ((s = alloc((void**)&ix->d_layer_off, IDIST_MAX_LAYERS * 8)) != IDIST_OK) return cleanup(s);
+    if (hipMemcpy(ix->d_layer_off, ix->layer_off, IDIST_MAX_LAYERS * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(ix->d_zero, 0xFF, std::max<size_t>((size_t)n * IDIST_M2 * 4, 4)) != hipSuccess ||
+        hipMemset(ix->d_upper, 0xFF, std::max<size_t>(rows * IDIST_M * 4, 4)) != hipSuccess)
+        return cleanup(fail(IDIST_ERR_HIP, "index initialisation failed: %s", hipGetErrorString(hipGetLastError())));
+    *out = ix;
+    return IDIST_OK;
+}
+
+// natural row-major device points -> blocked rows of the index
+idist_status load_points_device(idist_index* ix, const float* d_nat) {
+    if (ix->n == 0) return IDIST_OK;
+    const size_t total = (size_t)ix->n * ix->L.stride;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
+    IDIST_LAUNCH(permute_rows_kernel, grid, 256, 0, (hipStream_t) nullptr, d_nat, ix->d_points, ix->n, ix->dim, ix->L.stride, ix->L.nb);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return IDIST_OK;
+}
+idist_status load_points_host(idist_index* ix, const float* h_nat) {
+    if (ix->n == 0) return IDIST_OK;
+    float* d_nat = nullptr;
+    const size_t bytes = (size_t)ix->n * ix->dim * 4;
+    HIPCHK(hipMalloc((void**)&d_nat, bytes));
+    hipError_t e = hipMemcpy(d_nat, h_nat, bytes, hipMemcpyHostToDevice);
+    idist_status s = e == hipSuccess ? load_points_device(ix, d_nat)
+                                     : fail(IDIST_ERR_HIP, "hipMemcpy(points): %s", hipGetErrorString(e));
+    hipFree(d_nat);
+    return s;
+}
+
+uint32_t default_slots(const idist_index* ix) {
+    // fill the chip (16 single-wave workgroups per CU) within a visited-set memory budget
+    size_t freeb = 0, totalb = 0;
+    if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) freeb = (size_t)8 << 30;
+    const size_t budget = std::min<size_t>(freeb / 4, (size_t)32 << 30);
+    const size_t vis = (((size_t)ix->n + 255) & ~(size_t)255);
+    size_t s = (size_t)ix->n_cu * 16;
+    if (vis) s = std::min(s, std::max<size_t>(budget / vis, 64));
+    return (uint32_t)std::max<size_t>(s, 1);
+}
+
+idist_status device_status_to_code(uint32_t st) {
+    if (st & kStBadRow) return fail(IDIST_ERR_BAD_GRAPH, "device met an adjacency id >= n");
+    if (st & kStTieOverflow)
+        return fail(IDIST_ERR_TIE_OVERFLOW, "more than %d live equidistant candidates beyond ef", kTieCap);
+    if (st & kStGuard) return fail(IDIST_ERR_INTERNAL, "device-side loop guard tripped");
+    return IDIST_OK;
+}
+
+// ---- build driver: the per-layer insertion schedule of Hnsw::new, core/lib.rs:304-329 ----
+idist_status run_build(idist_index* ix) {
+    const uint32_t n = ix->n;
+    if (n <= 1) return IDIST_OK;   // pid 0 is never inserted (core/lib.rs:279-280)
+    const idist_config& cfg = ix->cfg;
+    const uint32_t top = ix->n_upper;
+    const uint32_t cap = cfg.max_batch == 0 ? 8192u : cfg.max_batch;
+    const uint32_t slots_max = default_slots(ix);
+    const uint32_t slots = std::min(cap, slots_max);
+    const size_t vis_stride = ((size_t)n + 255) & ~(size_t)255;
+    const uint32_t wcap = cfg.ef_construction + 64 + kTieCap + 64;
+    const size_t smem = smem_bytes(ix->L.stride, wcap, true);
+    if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave (> 64 KiB)", smem);
+
+    uint8_t *d_vis = nullptr, *d_gen = nullptr;
+    uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
+    uint32_t* d_small = nullptr;           // [0] n_touched, [1..2] queue, [3] status
+    unsigned long long* d_stats = nullptr; // [8]
+    const size_t n_edges = (size_t)cap * IDIST_M2;
+    const size_t n_touch = std::min<size_t>(n_edges, n);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto release = [&]() {
+        hipFree(d_vis); hipFree(d_gen); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
+        hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+    };
+#define BCHK(expr)                                                                                  \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            release();                                                                              \
+            return fail(IDIST_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                           \
+    } while (0)
+    BCHK(hipMalloc((void**)&d_vis, (size_t)slots * vis_stride));
+    BCHK(hipMemset(d_vis, 0, (size_t)slots * vis_stride));
+    BCHK(hipMalloc((void**)&d_gen, std::max<size_t>(slots, 256)));
+    BCHK(hipMemset(d_gen, 0, std::max<size_t>(slots, 256)));
+    BCHK(hipMalloc((void**)&d_edge_pid, n_edges * 4));
+    BCHK(hipMalloc((void**)&d_edge_dist, n_edges * 4));
+    BCHK(hipMalloc((void**)&d_next, n_edges * 4));
+    BCHK(hipMalloc((void**)&d_head, (size_t)n * 4));
+    BCHK(hipMemset(d_head, 0xFF, (size_t)n * 4));
+    BCHK(hipMalloc((void**)&d_touched, n_touch * 4));
+    BCHK(hipMalloc((void**)&d_small, 256));
+    BCHK(hipMemset(d_small, 0, 256));
+    BCHK(hipMalloc((void**)&d_stats, 64));
+    BCHK(hipMemset(d_stats, 0, 64));
+    BCHK(hipEventCreate(&e0));
+    BCHK(hipEventCreate(&e1));
+
+    IndexView view = ix->view();
+    BuildArgs a{};
+    a.top = top;
+    a.efc = cfg.ef_construction;
+    a.wcap = wcap;
+    a.keep_pruned = cfg.keep_pruned ? 1u : 0u;
+    a.visited = d_vis;
+    a.vis_stride = vis_stride;
+    a.gen = d_gen;
+    a.edge_pid = d_edge_pid;
+    a.edge_dist = d_edge_dist;
+    a.head = d_head;
+    a.next = d_next;
+    a.touched = d_touched;
+    a.n_touched = d_small;
+    a.queue = d_small + 1;
+    a.status = d_small + 3;
+    a.stats = d_stats;
+
+    uint32_t cum[IDIST_MAX_LAYERS + 1];
+    cum[0] = n;
+    for (uint32_t l = 1; l <= top; l++) cum[l] = ix->layer_len[l - 1];
+
+    hipStream_t stream = nullptr;
+    uint64_t n_batches = 0;
+    BCHK(hipEventRecord(e0, stream));
+    for (int layer = (int)top; layer >= 0; layer--) {                    // core/lib.rs:304
+        const uint32_t end = cum[layer];
+        uint32_t g = (uint32_t)layer == top ? 1u : std::max(cum[layer + 1], 1u);   // ranges, :275-281
+        a.layer = (uint32_t)layer;
+        while (g < end) {
+            // top layer is sequential in the reference (:313-314); below, at most `cap` inserts run
+            // concurrently (:316-318) and never more than 1/32 of the graph they search.
+            uint32_t B = 1;
+            if (cap > 1 && (uint32_t)layer != top && g >= 64) B = std::min(cap, g / 32u);
+            B = std::min(B, end - g);
+            a.start = g;
+            a.count = B;
+            BCHK(hipMemsetAsync(d_small, 0, 12, stream));   // n_touched + both queue heads
+            const uint32_t gridA = std::min(B, slots);
+            const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
+#define LAUNCH_BUILD(NB_, RS_, TAIL_)                                                              \
+    {                                                                                              \
+        auto kA = build_insert_kernel<NB_, RS_, TAIL_>;                                            \
+        auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
+        IDIST_LAUNCH(kA, gridA, 64, smem, stream, view, a);                                        \
+        IDIST_LAUNCH(kB, gridB, 64, smem, stream, view, a);                                        \
+    }
+            IDIST_DISPATCH(ix->L, LAUNCH_BUILD);
+#undef LAUNCH_BUILD
+            g += B;
+            n_batches++;
+            if ((n_batches & 1023u) == 0) BCHK(hipGetLastError());
+        }
+        if (layer > 0) {                                                 // UpperNode::from_zero, :323-328
+            const size_t total = (size_t)end * IDIST_M;
+            const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
+            IDIST_LAUNCH(snapshot_kernel, grid, 256, 0, stream, ix->d_zero, ix->d_upper + ix->layer_off[layer - 1] * IDIST_M, end);
+        }
+    }
+    BCHK(hipEventRecord(e1, stream));
+    BCHK(hipGetLastError());
+    BCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    BCHK(hipEventElapsedTime(&ms, e0, e1));
+    uint32_t small[4] = {0, 0, 0, 0};
+    unsigned long long stats[8] = {0};
+    BCHK(hipMemcpy(small, d_small, 16, hipMemcpyDeviceToHost));
+    BCHK(hipMemcpy(stats, d_stats, 64, hipMemcpyDeviceToHost));
+#undef BCHK
+    release();
+    ix->stats.n_dist = stats[0];
+    ix->stats.n_exp0 = stats[1];
+    ix->stats.n_expU = stats[2];
+    ix->stats.n_heur_dist = stats[3];
+    ix->stats.n_heur_rows = stats[4];
+    ix->stats.n_updates = stats[5];
+    ix->stats.n_batches = n_batches;
+    ix->stats.seconds = ms * 1e-3;
+    return device_status_to_code(small[3]);
+}
+
+idist_status build_common(const void* points, bool on_device, uint32_t n, uint32_t dim, const idist_config* cfg,
+                          int32_t device, idist_index** out) {
+    CHK(validate_config(cfg, true));
+    if (!points && n) return fail(IDIST_ERR_INVALID_ARG, "points is null");
+    uint32_t cum[IDIST_MAX_LAYERS + 1];
+    uint32_t nl = 1;
+    cum[0] = n;
+    if (n) {
+        nl = layer_sizes(n, cfg->ml, cum, IDIST_MAX_LAYERS);
+        if (nl == 0) return fail(IDIST_ERR_INVALID_ARG, "ml = %g yields more than %u layers", (double)cfg->ml, IDIST_MAX_LAYERS);
+    }
+    idist_index* ix = nullptr;
+    CHK(index_alloc(n, dim, cfg, cum + 1, n ? nl - 1 : 0, device, &ix));
+    idist_status s = on_device ? load_points_device(ix, (const float*)points) : load_points_host(ix, (const float*)points);
+    if (s == IDIST_OK) s = run_build(ix);
+    if (s != IDIST_OK) { idist_index_free(ix); return s; }
+    *out = ix;
+    return IDIST_OK;
+}
+
+idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
+                           uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream) {
+    const uint32_t ef = ix->cfg.ef_search;
+    SearchArgs a{};
+    a.queries = d_q;
+    a.nq = nq;
+    a.ef = ef;
+    a.wcap = ef + 64 + kTieCap + 8;
+    a.out_pid = d_pid;
+    a.out_dist = d_dist;
+    a.out_count = d_cnt;
+    a.out_counters = d_ctr;
+    a.visited = ctx->d_visited;
+    a.vis_stride = ctx->vis_stride;
+    a.gen = ctx->d_gen;
+    a.next = ctx->d_next;
+    a.status = ctx->d_next + 1;
+    const size_t smem = smem_bytes(ix->L.stride, a.wcap, false);
+    if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_search need %zu B of LDS per wave (> 64 KiB)", smem);
+    const uint32_t grid = std::min(nq, ctx->slots);
+    IndexView view = ix->view();
+    HIPCHK(hipMemsetAsync(ctx->d_next, 0, 4, stream));
+    HIPCHK(hipEventRecord(ctx->ev0, stream));
+#define LAUNCH_SEARCH(NB_, RS_, TAIL_)                      \
+    {                                                       \
+        auto kS = search_kernel<NB_, RS_, TAIL_>;           \
+        IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);  \
+    }
+    IDIST_DISPATCH(ix->L, LAUNCH_SEARCH);
+#undef LAUNCH_SEARCH
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev1, stream));
+    ctx->timed = true;
+    return IDIST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* idist_last_error(void) { return g_err.c_str(); }
+const char* idist_version(void) { return "instant-distance_amd 0.1 (gfx950)"; }
+
+idist_status idist_device_count(int32_t* out) {
+    if (!out) return fail(IDIST_ERR_INVALID_ARG, "out is null");
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) cnt = 0;
+    *out = cnt;
+    return IDIST_OK;
+}
+
+idist_status idist_default_config(idist_config* cfg) {   // core/lib.rs:101-128
+    if (!cfg) return fail(IDIST_ERR_INVALID_ARG, "cfg is null");
+    cfg->ef_search = 100;
+    cfg->ef_construction = 100;
+    cfg->ml = 1.0f / logf((float)IDIST_M);
+    cfg->has_heuristic = 1;
+    cfg->extend_candidates = 0;
+    cfg->keep_pruned = 1;
+    cfg->metric = IDIST_METRIC_L2SQ;
+    cfg->max_batch = 0;
+    return IDIST_OK;
+}
+
+idist_status idist_layer_sizes(uint32_t n, float ml, uint32_t* cum, uint32_t cap, uint32_t* n_layers) {
+    if (!cum || !n_layers) return fail(IDIST_ERR_INVALID_ARG, "null output");
+    uint32_t tmp[IDIST_MAX_LAYERS + 1];
+    const uint32_t nl = n ? layer_sizes(n, ml, tmp, IDIST_MAX_LAYERS) : 0;
+    if (n && nl == 0) return fail(IDIST_ERR_INVALID_ARG, "more than %u layers", IDIST_MAX_LAYERS);
+    if (nl > cap) return fail(IDIST_ERR_INVALID_ARG, "cum holds %u entries, %u needed", cap, nl);
+    for (uint32_t i = 0; i < nl; i++) cum[i] = tmp[i];
+    *n_layers = nl;
+    return IDIST_OK;
+}
+
+idist_status idist_permutation(uint64_t seed, uint32_t n, uint32_t* out_pid, uint32_t* order) {
+    // SmallRng (xoshiro256++) seeded through SplitMix64; PARITY UNPINNED, see idist.h
+    uint64_t st = seed, s[4];
+    for (int i = 0; i < 4; i++) {
+        uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        s[i] = z ^ (z >> 31);
+    }
+    auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
+    auto next_u32 = [&]() {
+        const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t; s[3] = rotl(s[3], 45);
+        return (uint32_t)(result >> 32);
+    };
+    std::vector<std::pair<uint32_t, uint32_t>> sh(n);
+    for (uint32_t i = 0; i < n; i++) {                       // core/lib.rs:257-259
+        const uint64_t m = (uint64_t)next_u32() * n;
+        uint32_t key = (uint32_t)(m >> 32);
+        const uint32_t lo = (uint32_t)m;
+        if (lo > (uint32_t)(0u - n)) {
+            const uint32_t hi2 = (uint32_t)(((uint64_t)next_u32() * n) >> 32);
+            if ((uint64_t)lo + hi2 > 0xFFFFFFFFull) key += 1;
+        }
+        sh[i] = {key, i};
+    }
+    std::sort(sh.begin(), sh.end());                         // sort_unstable, :260 (all pairs distinct)
+    for (uint32_t i = 0; i < n; i++) {                       // :262-270
+        if (out_pid) out_pid[sh[i].second] = i;
+        if (order) order[i] = sh[i].second;
+    }
+    return IDIST_OK;
+}
+
+idist_status idist_index_build(const float* points, uint32_t n, uint32_t dim, const idist_config* cfg,
+                               int32_t device, idist_index** out) {
+    if (!out) return fail(IDIST_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    return build_common(points, false, n, dim, cfg, device, out);
+}
+
+idist_status idist_index_build_device(const void* d_points, uint32_t n, uint32_t dim, const idist_config* cfg,
+                                      int32_t device, idist_index** out) {
+    if (!out) return fail(IDIST_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    return build_common(d_points, true, n, dim, cfg, device, out);
+}
+
+idist_status idist_index_build_stats(const idist_index* idx, idist_build_stats* out) {
+    if (!idx || !out) return fail(IDIST_ERR_INVALID_ARG, "null argument");
+    *out = idx->stats;
+    return IDIST_OK;
+}
+
+idist_status idist_index_import(const float* points, uint32_t n, uint32_t dim, const idist_config* cfg,
+                                const uint32_t* zero, const uint32_t* const* layers, const uint32_t* layer_len,
+                                uint32_t n_upper, int32_t device, idist_index** out) {
+    if (!out) return fail(IDIST_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    CHK(validate_config(cfg, false));
+    if (n && (!points || !zero)) return fail(IDIST_ERR_INVALID_ARG, "points/zero is null");
+    if (n_upper && (!layers || !layer_len)) return fail(IDIST_ERR_INVALID_ARG, "layers/layer_len is null");
+    for (uint32_t l = 0; l < n_upper; l++)
+        if (layer_len[l] == 0 || layer_len[l] > n || (l && layer_len[l] > layer_len[l - 1]))
+            return fail(IDIST_ERR_BAD_GRAPH, "layer_len[%u] = %u: layers must nest (core/lib.rs:323-327)", l, layer_len[l]);
+    idist_index* ix = nullptr;
+    CHK(index_alloc(n, dim, cfg, layer_len, n_upper, device, &ix));
+    auto bail = [&](idist_status s) { idist_index_free(ix); return s; };
+    idist_status s = load_points_host(ix, points);
+    if (s != IDIST_OK) return bail(s);
+    if (n) {
+        if (hipMemcpy(ix->d_zero, zero, (size_t)n * IDIST_M2 * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(IDIST_ERR_HIP, "hipMemcpy(zero) failed"));
+        for (uint32_t l = 0; l < n_upper; l++)
+            if (hipMemcpy(ix->d_upper + ix->layer_off[l] * IDIST_M, layers[l], (size_t)layer_len[l] * IDIST_M * 4,
+                          hipMemcpyHostToDevice) != hipSuccess)
+                return bail(fail(IDIST_ERR_HIP, "hipMemcpy(layer %u) failed", l + 1));
+        // validate against the reference's invariants
+        uint32_t* d_bad = nullptr;
+        if (hipMalloc((void**)&d_bad, 256) != hipSuccess || hipMemset(d_bad, 0, 256) != hipSuccess)
+            return bail(fail(IDIST_ERR_HIP, "hipMalloc(validate) failed"));
+        IDIST_LAUNCH(validate_rows_kernel, std::min<uint32_t>(n, 8192), 64, 0, (hipStream_t) nullptr, ix->d_zero, n, kM2, n, d_bad);
+        for (uint32_t l = 0; l < n_upper; l++)
+            IDIST_LAUNCH(validate_rows_kernel, std::min<uint32_t>(layer_len[l], 8192), 64, 0, (hipStream_t) nullptr,
+                         ix->d_upper + ix->layer_off[l] * IDIST_M, layer_len[l], kM, layer_len[l], d_bad);
+        uint32_t bad = 0;
+        hipError_t e = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
+        hipFree(d_bad);
+        if (e != hipSuccess) return bail(fail(IDIST_ERR_HIP, "validate: %s", hipGetErrorString(e)));
+        if (bad)
+            return bail(fail(IDIST_ERR_BAD_GRAPH,
+                             "%u adjacency rows hold an id outside their layer or a duplicate id", bad));
+    }
+    *out = ix;
+    return IDIST_OK;
+}
+
+idist_status idist_index_alloc(uint32_t n, uint32_t dim, const idist_config* cfg, const uint32_t* layer_len,
+                               uint32_t n_upper, int32_t device, idist_index** out) {
+    CHK(validate_config(cfg, false));
+    if (n_upper && !layer_len) return fail(IDIST_ERR_INVALID_ARG, "layer_len is null");
+    return index_alloc(n, dim, cfg, layer_len, n_upper, device, out);
+}
+
+idist_status idist_index_export(const idist_index* idx, uint32_t* zero, uint32_t* const* layers) {
+    if (!idx) return fail(IDIST_ERR_INVALID_ARG, "idx is null");
+    HIPCHK(hipSetDevice(idx->device));
+    if (idx->n) {
+        if (!zero) return fail(IDIST_ERR_INVALID_ARG, "zero is null");
+        HIPCHK(hipMemcpy(zero, idx->d_zero, (size_t)idx->n * IDIST_M2 * 4, hipMemcpyDeviceToHost));
+    }
+    for (uint32_t l = 0; l < idx->n_upper; l++) {
+        if (!layers || !layers[l]) return fail(IDIST_ERR_INVALID_ARG, "layers[%u] is null", l);
+        HIPCHK(hipMemcpy(layers[l], idx->d_upper + idx->layer_off[l] * IDIST_M, (size_t)idx->layer_len[l] * IDIST_M * 4,
+                         hipMemcpyDeviceToHost));
+    }
+    return IDIST_OK;
+}
+
+idist_status idist_index_get_info(const idist_index* idx, idist_index_info* out) {
+    if (!idx || !out) return fail(IDIST_ERR_INVALID_ARG, "null argument");
+    memset(out, 0, sizeof(*out));
+    out->n = idx->n;
+    out->dim = idx->dim;
+    out->row_stride = idx->L.stride;
+    out->n_upper = idx->n_upper;
+    out->ef_search = idx->cfg.ef_search;
+    out->metric = idx->cfg.metric;
+    out->device = idx->device;
+    for (uint32_t l = 0; l < idx->n_upper; l++) out->layer_len[l] = idx->layer_len[l];
+    return IDIST_OK;
+}
+
+idist_status idist_index_device_buffers(const idist_index* idx, idist_device_buffers* out) {
+    if (!idx || !out) return fail(IDIST_ERR_INVALID_ARG, "null argument");
+    out->points = idx->d_points;
+    out->points_bytes = (size_t)idx->n * idx->L.stride * 4;
+    out->zero = idx->d_zero;
+    out->zero_bytes = (size_t)idx->n * IDIST_M2 * 4;
+    out->upper = idx->d_upper;
+    out->upper_bytes = idx->upper_rows * IDIST_M * 4;
+    return IDIST_OK;
+}
+
+idist_status idist_index_set_ef_search(idist_index* idx, uint32_t ef_search) {
+    if (!idx) return fail(IDIST_ERR_INVALID_ARG, "idx is null");
+    if (ef_search > IDIST_MAX_EF) return fail(IDIST_ERR_INVALID_ARG, "ef_search %u > %u", ef_search, IDIST_MAX_EF);
+    idx->cfg.ef_search = ef_search;
+    return IDIST_OK;
+}
+
+void idist_index_free(idist_index* idx) {
+    if (!idx) return;
+    hipSetDevice(idx->device);
+    hipFree(idx->d_points);
+    hipFree(idx->d_zero);
+    hipFree(idx->d_upper);
+    hipFree(idx->d_layer_off);
+    delete idx;
+}
+
+idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_search_ctx** out) {
+    if (!idx || !out) return fail(IDIST_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(idx->device));
+    idist_search_ctx* c = new idist_search_ctx();
+    c->idx = idx;
+    c->slots = slots ? slots : default_slots(idx);
+    c->vis_stride = ((size_t)idx->n + 255) & ~(size_t)255;
+    auto bail = [&](hipError_t e) {
+        idist_search_ctx_free(c);
+        return fail(IDIST_ERR_HIP, "search ctx allocation failed: %s", hipGetErrorString(e));
+    };
+    hipError_t e;
+    const size_t vb = std::max<size_t>((size_t)c->slots * c->vis_stride, 256);
+    if ((e = hipMalloc((void**)&c->d_visited, vb)) != hipSuccess) return bail(e);
+    if ((e = hipMemset(c->d_visited, 0, vb)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc((void**)&c->d_gen, std::max<size_t>(c->slots, 256))) != hipSuccess) return bail(e);
+    if ((e = hipMemset(c->d_gen, 0, std::max<size_t>(c->slots, 256))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc((void**)&c->d_next, 256)) != hipSuccess) return bail(e);
+    if ((e = hipMemset(c->d_next, 0, 256)) != hipSuccess) return bail(e);
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e);
+    *out = c;
+    return IDIST_OK;
+}
+
+void idist_search_ctx_free(idist_search_ctx* c) {
+    if (!c) return;
+    if (c->idx) hipSetDevice(c->idx->device);
+    hipFree(c->d_visited);
+    hipFree(c->d_gen);
+    hipFree(c->d_next);
+    hipFree(c->d_q);
+    hipFree(c->d_pid);
+    hipFree(c->d_dist);
+    hipFree(c->d_cnt);
+    hipFree(c->d_ctr);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+idist_status idist_search_batch_device(const idist_index* idx, idist_search_ctx* ctx, const void* d_queries,
+                                       uint32_t nq, void* d_out_pid, void* d_out_dist, void* d_out_count,
+                                       void* d_out_counters, void* hip_stream) {
+    if (!idx || !ctx || ctx->idx != idx) return fail(IDIST_ERR_INVALID_ARG, "ctx does not belong to idx");
+    if (nq == 0) return IDIST_OK;
+    if (!d_queries || !d_out_count) return fail(IDIST_ERR_INVALID_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (idx->n == 0 || idx->cfg.ef_search == 0) {   // core/lib.rs:359-361
+        HIPCHK(hipMemsetAsync(d_out_count, 0, (size_t)nq * 4, stream));
+        return IDIST_OK;
+    }
+    if (!d_out_pid || !d_out_dist) return fail(IDIST_ERR_INVALID_ARG, "null device pointer");
+    return launch_search(idx, ctx, (const float*)d_queries, nq, (uint32_t*)d_out_pid, (float*)d_out_dist,
+                         (uint32_t*)d_out_count, (uint32_t*)d_out_counters, stream);
+}
+
+idist_status idist_search_ctx_status(idist_search_ctx* ctx) {
+    if (!ctx) return fail(IDIST_ERR_INVALID_ARG, "ctx is null");
+    uint32_t st = 0;
+    HIPCHK(hipMemcpy(&st, ctx->d_next + 1, 4, hipMemcpyDeviceToHost));
+    if (st) HIPCHK(hipMemset(ctx->d_next + 1, 0, 4));
+    return device_status_to_code(st);
+}
+
+idist_status idist_search_ctx_last_kernel_ms(idist_search_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return fail(IDIST_ERR_INVALID_ARG, "null argument");
+    if (!ctx->timed) return fail(IDIST_ERR_INVALID_ARG, "no search kernel has been launched on this ctx");
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return IDIST_OK;
+}
+
+idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, const float* queries, uint32_t nq,
+                                uint32_t* out_pid, float* out_dist, uint32_t* out_count, uint32_t* out_counters) {
+    if (!idx || !ctx || ctx->idx != idx) return fail(IDIST_ERR_INVALID_ARG, "ctx does not belong to idx");
+    if (nq == 0) return IDIST_OK;
+    if (!queries || !out_count) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
+    const uint32_t ef = idx->cfg.ef_search;
+    if (idx->n == 0 || ef == 0) {
+        memset(out_count, 0, (size_t)nq * 4);
+        if (out_counters) memset(out_counters, 0, (size_t)nq * 12);
+        return IDIST_OK;
+    }
+    if (!out_pid || !out_dist) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
+    HIPCHK(hipSetDevice(idx->device));
+    const size_t qb = (size_t)nq * idx->dim * 4, ob = (size_t)nq * ef * 4;
+    if (qb > ctx->cap_q) { hipFree(ctx->d_q); ctx->d_q = nullptr; ctx->cap_q = 0; HIPCHK(hipMalloc((void**)&ctx->d_q, qb)); ctx->cap_q = qb; }
+    if (ob > ctx->cap_out) {
+        hipFree(ctx->d_pid); hipFree(ctx->d_dist); ctx->d_pid = nullptr; ctx->d_dist = nullptr; ctx->cap_out = 0;
+        HIPCHK(hipMalloc((void**)&ctx->d_pid, ob));
+        HIPCHK(hipMalloc((void**)&ctx->d_dist, ob));
+        ctx->cap_out = ob;
+    }
+    if (nq > ctx->cap_nq) {
+        hipFree(ctx->d_cnt); hipFree(ctx->d_ctr); ctx->d_cnt = nullptr; ctx->d_ctr = nullptr; ctx->cap_nq = 0;
+        HIPCHK(hipMalloc((void**)&ctx->d_cnt, (size_t)nq * 4));
+        HIPCHK(hipMalloc((void**)&ctx->d_ctr, (size_t)nq * 12));
+        ctx->cap_nq = nq;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_q, queries, qb, hipMemcpyHostToDevice, ctx->stream));
+    CHK(launch_search(idx, ctx, ctx->d_q, nq, ctx->d_pid, ctx->d_dist, ctx->d_cnt, out_counters ? ctx->d_ctr : nullptr,
+                      ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_pid, ctx->d_pid, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_dist, ctx->d_dist, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_count, ctx->d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_counters) HIPCHK(hipMemcpyAsync(out_counters, ctx->d_ctr, (size_t)nq * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return idist_search_ctx_status(ctx);
+}
+
+idist_status idist_distance_batch(const idist_index* idx, const float* queries, uint32_t nq, const uint32_t* ids,
+                                  uint32_t n_ids, float* out_dist) {
+    if (!idx) return fail(IDIST_ERR_INVALID_ARG, "idx is null");
+    if (nq == 0 || n_ids == 0) return IDIST_OK;
+    if (!queries || !ids || !out_dist) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
+    HIPCHK(hipSetDevice(idx->device));
+    float *d_q = nullptr, *d_out = nullptr;
+    uint32_t* d_ids = nullptr;
+    const size_t qb = (size_t)nq * idx->dim * 4, ib = (size_t)nq * n_ids * 4;
+    auto release = [&]() { hipFree(d_q); hipFree(d_out); hipFree(d_ids); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_q, qb)) != hipSuccess || (e = hipMalloc((void**)&d_out, ib)) != hipSuccess ||
+        (e = hipMalloc((void**)&d_ids, ib)) != hipSuccess ||
+        (e = hipMemcpy(d_q, queries, qb, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_ids, ids, ib, hipMemcpyHostToDevice)) != hipSuccess) {
+        release();
+        return fail(IDIST_ERR_HIP, "distance_batch staging: %s", hipGetErrorString(e));
+    }
+    const uint32_t chunks = (n_ids + 63u) / 64u;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)nq * chunks, 1u << 20);
+    const size_t smem = smem_bytes(idx->L.stride, 0, false);
+    IndexView view = idx->view();
+#define LAUNCH_DIST(NB_, RS_, TAIL_)                                                              \
+    {                                                                                             \
+        auto kD = distance_batch_kernel<NB_, RS_, TAIL_>;                                         \
+        IDIST_LAUNCH(kD, grid, 64, smem, (hipStream_t) nullptr, view, d_q, nq, d_ids, n_ids, d_out); \
+    }
+    IDIST_DISPATCH(idx->L, LAUNCH_DIST);
+#undef LAUNCH_DIST
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(out_dist, d_out, ib, hipMemcpyDeviceToHost)) != hipSuccess) {
+        release();
+        return fail(IDIST_ERR_HIP, "distance_batch: %s", hipGetErrorString(e));
+    }
+    release();
+    return IDIST_OK;
+}
+
+idist_status idist_bruteforce(const idist_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                              uint32_t* out_pid, float* out_dist) {
+    if (!idx) return fail(IDIST_ERR_INVALID_ARG, "idx is null");
+    if (nq == 0) return IDIST_OK;
+    if (k == 0 || k > IDIST_MAX_EF) return fail(IDIST_ERR_INVALID_ARG, "k %u out of [1,%u]", k, IDIST_MAX_EF);
+    if (!queries || !out_pid || !out_dist) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
+    HIPCHK(hipSetDevice(idx->device));
+    float *d_q = nullptr, *d_dist = nullptr;
+    uint32_t *d_pid = nullptr, *d_next = nullptr;
+    const size_t qb = (size_t)nq * idx->dim * 4, ob = (size_t)nq * k * 4;
+    auto release = [&]() { hipFree(d_q); hipFree(d_dist); hipFree(d_pid); hipFree(d_next); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_q, qb)) != hipSuccess || (e = hipMalloc((void**)&d_dist, ob)) != hipSuccess ||
+        (e = hipMalloc((void**)&d_pid, ob)) != hipSuccess || (e = hipMalloc((void**)&d_next, 256)) != hipSuccess ||
+        (e = hipMemset(d_next, 0, 256)) != hipSuccess ||
+        (e = hipMemcpy(d_q, queries, qb, hipMemcpyHostToDevice)) != hipSuccess) {
+        release();
+        return fail(IDIST_ERR_HIP, "bruteforce staging: %s", hipGetErrorString(e));
+    }
+    const uint32_t wcap = k + 64 + 8;
+    const size_t smem = smem_bytes(idx->L.stride, wcap, false);
+    const uint32_t grid = std::min<uint32_t>(nq, (uint32_t)idx->n_cu * 16);
+    IndexView view = idx->view();
+#define LAUNCH_BF(NB_, RS_, TAIL_)                                                                          \
+    {                                                                                                       \
+        auto kF = bruteforce_kernel<NB_, RS_, TAIL_>;                                                       \
+        IDIST_LAUNCH(kF, grid, 64, smem, (hipStream_t) nullptr, view, d_q, nq, k, wcap, d_pid, d_dist, d_next); \
+    }
+    IDIST_DISPATCH(idx->L, LAUNCH_BF);
+#undef LAUNCH_BF
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(out_pid, d_pid, ob, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(out_dist, d_dist, ob, hipMemcpyDeviceToHost)) != hipSuccess) {
+        release();
+        return fail(IDIST_ERR_HIP, "bruteforce: %s", hipGetErrorString(e));
+    }
+    release();
+    return IDIST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,417 @@
+// idist_device.hpp — wave64 device routines of the HNSW hot path for gfx950.
+//
+// One wavefront (= one 64-thread workgroup) owns one query / one insertion.
+// Nothing here is a translation of the reference's data structures; the
+// reference semantics that must be reproduced bit-for-bit are cited inline
+// (paths relative to /root/reference/, core/ = instant-distance/src/).
+//
+//   * canonical distance  : 8 lanes per point row, lane j runs FMA chain j of
+//                           instant-distance-py/src/lib.rs:390-411; 8 rows per
+//                           wave instruction, each row read as one 128-B line.
+//   * W (Search.nearest)  : ONE sorted u64 array in LDS, key = dist_bits<<32 |
+//                           pid, bit 63 = "already expanded".  The candidate
+//                           heap of core/lib.rs:564 is not materialised: the
+//                           live candidates are exactly the un-expanded entries
+//                           of that array (DESIGN.md §search-state proves the
+//                           equivalence, tests/test_wstate_model.py checks it).
+//   * visited             : one generation-stamped byte per point per slot in
+//                           HBM (core/types.rs:13-59), clear = generation += 1.
+#pragma once
+#ifdef IDIST_EMU
+#include "hip_emu.hpp"   // tests/simt: CPU lockstep emulation of one wave (test infrastructure)
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+#ifdef IDIST_EMU
+#define IDIST_DYN_SMEM(name) uint8_t* name = ::emu::cur_smem()
+#else
+#define IDIST_DYN_SMEM(name) extern __shared__ __align__(16) uint8_t name[]
+#endif
+
+namespace idist {
+
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+constexpr int kM = 32;
+constexpr int kM2 = 64;
+constexpr uint64_t kFlag = 1ull << 63;   // entry already expanded
+constexpr uint64_t kKeyMask = ~kFlag;
+constexpr int kTieCap = 64;              // live equidistant candidates kept beyond ef
+constexpr uint32_t kNanBits = 0x7fc00000u;
+constexpr uint64_t kMaxKey = 0x7fffffffffffffffull;
+
+enum : uint32_t { kStTieOverflow = 1u, kStGuard = 2u, kStBadRow = 4u };
+
+// Device view of an index (plain pointers; lives in kernel arguments).
+struct IndexView {
+    const float* points;      // [n][stride] blocked rows
+    uint32_t* zero;           // [n][64]
+    uint32_t* upper;          // [sum layer_len][32]; layer l (1-based) starts at row layer_off[l-1]
+    const uint64_t* layer_off;  // [n_upper]
+    uint32_t n, dim, stride;  // stride in floats, multiple of 16
+    uint32_t nb;              // full 32-float blocks (4 chain steps x 8 chains, transposed)
+    uint32_t rs;              // remaining chain steps (0..3), natural order
+    uint32_t tail;            // 1 if a 4-wide tail follows (padded dim % 8 == 4)
+    uint32_t n_upper;
+    uint32_t metric;          // 0 = squared L2, 1 = L2
+};
+
+// Position of natural element e inside a blocked row.
+__host__ __device__ inline uint32_t blocked_pos(uint32_t e, uint32_t nb) {
+    if (e < 32u * nb) {
+        uint32_t t = e >> 5, r = e & 31u, c = r >> 3, j = r & 7u;
+        return (t << 5) + (j << 2) + c;
+    }
+    return e;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }  // single-wave workgroup
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
+    uint32_t lo = bcast_u32((uint32_t)v, src), hi = bcast_u32((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ uint32_t canon_bits(float r, uint32_t metric) {
+    if (metric) r = __builtin_sqrtf(r);      // tests/all.rs:96; correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+    uint32_t b = __float_as_uint(r);
+    if (r != r) b = kNanBits;                // OrderedFloat: all NaN equal & greatest
+    return b;
+}
+
+// ---------------------------------------------------------------------------
+// Canonical distances of `na` rows (pids in act_pid[0..na)) to the LDS-resident
+// blocked vector q.  Result bits -> act_dist[0..na).  Group g = lane>>3 takes
+// row base+g, lane j = lane&7 runs chain j.  NB/RS/TAIL < 0 => runtime values.
+// ---------------------------------------------------------------------------
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q, const uint32_t* act_pid,
+                                            uint32_t* act_dist, int na) {
+    const int lane = lane_id();
+    const int g = lane >> 3, j = lane & 7;
+    const int nb = NB >= 0 ? NB : (int)ix.nb;
+    const int rs = RS >= 0 ? RS : (int)ix.rs;
+    const int tail = TAIL >= 0 ? TAIL : (int)ix.tail;
+    for (int base = 0; base < na; base += 8) {
+        const int k = base + g;
+        const bool on = k < na;
+        const uint32_t pid = on ? act_pid[k] : 0u;
+        const float* row = ix.points + (size_t)pid * ix.stride;
+        float acc = 0.0f;
+        if (on) {
+            if constexpr (NB >= 0) {
+                constexpr int CH = NB > 12 ? 8 : (NB > 0 ? NB : 1);
+#pragma unroll
+                for (int t0 = 0; t0 < NB; t0 += CH) {
+                    float4 p[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; u++)
+                        if (t0 + u < NB) p[u] = *reinterpret_cast<const float4*>(row + (t0 + u) * 32 + j * 4);
+#pragma unroll
+                    for (int u = 0; u < CH; u++) {
+                        if (t0 + u < NB) {
+                            const float4 w = *reinterpret_cast<const float4*>(q + (t0 + u) * 32 + j * 4);
+                            float d;
+                            d = w.x - p[u].x; acc = __builtin_fmaf(d, d, acc);
+                            d = w.y - p[u].y; acc = __builtin_fmaf(d, d, acc);
+                            d = w.z - p[u].z; acc = __builtin_fmaf(d, d, acc);
+                            d = w.w - p[u].w; acc = __builtin_fmaf(d, d, acc);
+                        }
+                    }
+                }
+            } else {
+                for (int t = 0; t < nb; t++) {
+                    const float4 p = *reinterpret_cast<const float4*>(row + t * 32 + j * 4);
+                    const float4 w = *reinterpret_cast<const float4*>(q + t * 32 + j * 4);
+                    float d;
+                    d = w.x - p.x; acc = __builtin_fmaf(d, d, acc);
+                    d = w.y - p.y; acc = __builtin_fmaf(d, d, acc);
+                    d = w.z - p.z; acc = __builtin_fmaf(d, d, acc);
+                    d = w.w - p.w; acc = __builtin_fmaf(d, d, acc);
+                }
+            }
+            for (int c = 0; c < rs; c++) {   // py/lib.rs:391-396, steps not filling a block
+                const int o = nb * 32 + c * 8 + j;
+                const float d = q[o] - row[o];
+                acc = __builtin_fmaf(d, d, acc);
+            }
+        }
+        // acc_4x = hi128 + lo128, py/lib.rs:398-400 (lanes j and j^4 hold the same sum)
+        float a4 = acc + __shfl_xor(acc, 4, 64);
+        if (tail && on) {                    // 4-wide tail, py/lib.rs:402-405
+            const int o = nb * 32 + rs * 8 + (j & 3);
+            const float d = q[o] - row[o];
+            a4 = __builtin_fmaf(d, d, a4);
+        }
+        const float s = a4 + __shfl_xor(a4, 2, 64);   // (s0+s2),(s1+s3): movehl+add, :407-408
+        const float r = s + __shfl_xor(s, 1, 64);     // add_ss, :409-411
+        if (on && j == 0) act_dist[k] = canon_bits(r, ix.metric);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Sorted-W state (Search.nearest + the live part of Search.candidates).
+//   W[0..min(plen,ef))  = Search.nearest (core/lib.rs:568)
+//   W[ef..plen)         = un-expanded candidates already truncated out of
+//                         `nearest` whose distance EQUALS nearest.last()'s —
+//                         the only truncated candidates the break test at
+//                         core/lib.rs:600-604 (distance-only, strict >) can
+//                         still expand.
+// ---------------------------------------------------------------------------
+struct WState {
+    uint64_t* W;     // LDS, capacity ef_cap + 64 + kTieCap
+    int plen;
+    int ef;
+    int cursor;      // lower bound of the first un-expanded entry
+    uint32_t status;
+};
+
+// number of entries with (masked) key < k  == Vec::binary_search Err(idx), core/lib.rs:712
+__device__ __forceinline__ int w_rank(const WState& st, uint64_t k) {
+    const int lane = lane_id();
+    int cnt = 0;
+    for (int i0 = 0; i0 < st.plen; i0 += 64) {
+        const int i = i0 + lane;
+        const bool lt = i < st.plen && (st.W[i] & kKeyMask) < k;
+        const int c = __popcll(__ballot(lt));
+        cnt += c;
+        if (c < 64) break;   // sorted: first chunk that is not all-less ends the count
+    }
+    return cnt;
+}
+
+// Vec::insert(idx, new), core/lib.rs:718 (the matching candidates.push is implicit)
+__device__ __forceinline__ void w_insert(WState& st, int idx, uint64_t k) {
+    const int lane = lane_id();
+    // shift [idx, plen) up by one, top chunk first so nothing is overwritten early
+    int hi = st.plen;
+    while (hi > idx) {
+        int lo = hi - 64;
+        if (lo < idx) lo = idx;
+        const int i = lo + lane;
+        uint64_t v = 0;
+        const bool act = i < hi;
+        if (act) v = st.W[i];
+        wave_sync();
+        if (act) st.W[i + 1] = v;
+        wave_sync();
+        hi = lo;
+    }
+    if (lane == 0) st.W[idx] = k;
+    wave_sync();
+    st.plen += 1;
+    if (idx < st.cursor) st.cursor = idx;
+}
+
+// first un-expanded entry at or after cursor, -1 if none (== candidates.pop() of the
+// minimum LIVE candidate, core/lib.rs:599; dead ones would only trigger the break)
+__device__ __forceinline__ int w_pop(WState& st) {
+    const int lane = lane_id();
+    for (int i0 = st.cursor; i0 < st.plen; i0 += 64) {
+        const int i = i0 + lane;
+        const bool open = i < st.plen && !(st.W[i] & kFlag);
+        const uint64_t m = __ballot(open);
+        if (m) {
+            const int idx = i0 + __builtin_ctzll(m);
+            st.cursor = idx;
+            return idx;
+        }
+    }
+    st.cursor = st.plen;
+    return -1;
+}
+
+// nearest.truncate(ef), core/lib.rs:612 — keeps, past ef, only live distance ties.
+__device__ __forceinline__ void w_truncate(WState& st) {
+    if (st.plen <= st.ef) return;
+    const int lane = lane_id();
+    if (st.ef == 0) { st.plen = 0; st.cursor = 0; return; }
+    const uint32_t fd = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32);
+    int out = st.ef;
+    for (int i0 = st.ef; i0 < st.plen; i0 += 64) {
+        const int i = i0 + lane;
+        uint64_t v = 0;
+        bool keep = false;
+        if (i < st.plen) {
+            v = st.W[i];
+            keep = !(v & kFlag) && (uint32_t)(v >> 32) == fd;
+        }
+        const uint64_t m = __ballot(keep);
+        wave_sync();
+        if (keep) st.W[out + __popcll(m & ((1ull << lane) - 1ull))] = v;
+        wave_sync();
+        out += __popcll(m);
+    }
+    if (out - st.ef > kTieCap) { st.status |= kStTieOverflow; out = st.ef + kTieCap; }
+    st.plen = out;
+    if (st.cursor > st.ef) st.cursor = st.ef;
+}
+
+// Search::cull, core/lib.rs:729-737: candidates := nearest, visited := pids(nearest)
+__device__ __forceinline__ void w_cull(WState& st) {
+    const int lane = lane_id();
+    if (st.plen > st.ef) st.plen = st.ef;
+    for (int i = lane; i < st.plen; i += 64) st.W[i] &= kKeyMask;
+    st.cursor = 0;
+    wave_sync();
+}
+
+// ---------------------------------------------------------------------------
+// Visited (core/types.rs:13-59) in HBM: one byte per point, per slot.
+// ---------------------------------------------------------------------------
+struct Visited {
+    uint8_t* store;
+    uint32_t n;
+    uint32_t gen;   // 1..255
+};
+__device__ __forceinline__ void visited_clear(Visited& v) {  // core/types.rs:48-58
+    if (v.gen < 255u) { v.gen += 1u; return; }
+    const int lane = lane_id();
+    uint4* p = reinterpret_cast<uint4*>(v.store);
+    const size_t n16 = ((size_t)v.n + 15u) / 16u;   // store is padded to 16 B
+    for (size_t i = lane; i < n16; i += 64) p[i] = make_uint4(0, 0, 0, 0);
+    __threadfence_block();
+    wave_sync();
+    v.gen = 1u;
+}
+
+struct Counters { uint32_t n_dist, n_exp0, n_expU; };
+
+// Search::push for the very first entry point (core/lib.rs:364, :444)
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, WState& st, Visited& vis,
+                                           uint32_t* act_pid, uint32_t* act_dist, Counters& ctr) {
+    const int lane = lane_id();
+    if (lane == 0) { act_pid[0] = 0u; vis.store[0] = (uint8_t)vis.gen; }
+    wave_sync();
+    dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, 1);
+    wave_sync();
+    if (lane == 0) st.W[0] = ((uint64_t)act_dist[0] << 32);  // pid 0
+    wave_sync();
+    st.plen = 1;
+    st.cursor = 0;
+    ctr.n_dist += 1;
+}
+
+// ---------------------------------------------------------------------------
+// Search::search (core/lib.rs:598-614) on one layer.  rows/row_stride: the
+// adjacency array (UpperNode: 32, ZeroNode: 64); links: `.take(links)`.
+// ---------------------------------------------------------------------------
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t* rows, int row_stride, int links,
+                                             const float* q, WState& st, Visited& vis, uint32_t* act_pid,
+                                             uint32_t* act_dist, Counters& ctr, bool is_zero) {
+    const int lane = lane_id();
+    uint32_t guard = 0;
+    for (;;) {
+        const int ci = w_pop(st);                         // :599-604
+        if (ci < 0) break;
+        const uint64_t c = st.W[ci];
+        wave_sync();
+        if (lane == 0) st.W[ci] = c | kFlag;
+        const uint32_t cpid = (uint32_t)c;
+        if (is_zero) ctr.n_exp0++; else ctr.n_expU++;
+
+        // layer.nearest_iter(pid).take(links): stop at first INVALID (core/types.rs:183-187)
+        uint32_t nb_pid = kInvalid;
+        if (lane < row_stride && lane < links) nb_pid = rows[(size_t)cpid * row_stride + lane];
+        const uint64_t inval = __ballot(nb_pid == kInvalid);
+        const int nvalid = inval ? __builtin_ctzll(inval) : 64;
+        const bool is_nb = lane < nvalid;
+
+        // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
+        bool fresh = false;
+        if (is_nb) {
+            if (nb_pid >= ix.n) {
+                st.status |= kStBadRow;
+            } else if (vis.store[nb_pid] != (uint8_t)vis.gen) {
+                vis.store[nb_pid] = (uint8_t)vis.gen;
+                fresh = true;
+            }
+        }
+        const uint64_t fm = __ballot(fresh);
+        const int na = __popcll(fm);
+        wave_sync();
+        if (na) {
+            if (fresh) act_pid[__popcll(fm & ((1ull << lane) - 1ull))] = nb_pid;   // keeps slot order
+            wave_sync();
+            dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);               // :709-710
+            wave_sync();
+            ctr.n_dist += (uint32_t)na;
+            uint64_t key = kMaxKey;
+            if (lane < na) key = ((uint64_t)act_dist[lane] << 32) | act_pid[lane];
+            // entries that cannot have rank < ef even now never will (W only improves)
+            const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
+            uint64_t pm = __ballot(lane < na && key < thr);
+            while (pm) {                                   // slot order, :606-608
+                const int i = __builtin_ctzll(pm);
+                pm &= pm - 1ull;
+                const uint64_t k = bcast_u64(key, i);
+                const int idx = w_rank(st, k);             // :712
+                if (idx < st.ef) w_insert(st, idx, k);     // :713-719
+            }
+        }
+        w_truncate(st);                                    // :612
+        if (++guard > ix.n + 64u) { st.status |= kStGuard; break; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Search::select_heuristic with extend_candidates = false (core/lib.rs:636-698).
+// Input: the first `nw` entries of st.W (sorted, = Search.nearest).  Output:
+// sel[0..return) = selected-then-backfilled keys (NOT re-sorted, Appendix A.10).
+// cq: LDS staging buffer for the candidate's own row (stride floats).
+// ---------------------------------------------------------------------------
+struct HeurCounters { uint32_t n_dist, n_rows; };
+
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ int select_heuristic(const IndexView& ix, const uint64_t* Wsrc, int nw, bool keep_pruned,
+                                                float* cq, uint64_t* sel, uint64_t* disc, uint32_t* act_pid,
+                                                uint32_t* act_dist, HeurCounters& hc) {
+    const int lane = lane_id();
+    int nsel = 0, ndis = 0;
+    for (int wi = 0; wi < nw; wi++) {                      // :668
+        if (nsel >= kM2) break;                            // :669-671
+        const uint64_t c = Wsrc[wi] & kKeyMask;
+        const uint32_t cd = (uint32_t)(c >> 32);
+        bool pruned = false;
+        if (nsel > 0) {
+            // stage points[candidate.pid] (:675) once, then 8 results per wave round
+            const float* crow = ix.points + (size_t)(uint32_t)c * ix.stride;
+            for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+                *reinterpret_cast<float4*>(cq + o) = *reinterpret_cast<const float4*>(crow + o);
+            hc.n_rows++;
+            wave_sync();
+            for (int b = 0; b < nsel && !pruned; b += 8) { // `any`, :676-679 (early exit per 8)
+                const int cnt = nsel - b < 8 ? nsel - b : 8;
+                if (lane < cnt) act_pid[lane] = (uint32_t)sel[b + lane];
+                wave_sync();
+                dist_rounds<NB, RS, TAIL>(ix, cq, act_pid, act_dist, cnt);
+                wave_sync();
+                hc.n_dist += (uint32_t)cnt;
+                const bool closer = lane < cnt && act_dist[lane] < cd;   // strict <, :678
+                pruned = __ballot(closer) != 0ull;
+                wave_sync();
+            }
+        }
+        if (lane == 0) {                                   // :681-684
+            if (!pruned) sel[nsel] = c;
+            else if (ndis < kM2) disc[ndis] = c;           // only the first 64 discarded can ever be back-filled
+        }
+        if (!pruned) nsel++; else ndis++;
+        wave_sync();
+    }
+    if (keep_pruned) {                                     // :687-695
+        int take = kM2 - nsel;
+        if (take > ndis) take = ndis;
+        if (lane < take) sel[nsel + lane] = disc[lane];
+        if (take > 0) nsel += take;
+        wave_sync();
+    }
+    return nsel;
+}
+
+}  // namespace idist

@@ -1,0 +1,451 @@
+// idist_kernels.hpp — gfx950 kernels of the HNSW hot path (search, build, layout).
+// Every kernel runs single-wave workgroups (blockDim.x == 64); grids are
+// persistent pools of "slots" that pull work items from an atomic queue.
+#pragma once
+#include "idist_device.hpp"
+
+namespace idist {
+
+// ---------------------------------------------------------------------------
+// layout: natural row-major [n][dim] -> blocked [n][stride]  
+// ---------------------------------------------------------------------------
+__global__ void permute_rows_kernel(const float* __restrict__ in, float* __restrict__ out, uint32_t n,
+                                    uint32_t dim, uint32_t stride, uint32_t nb) {
+    const size_t total = (size_t)n * stride;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(idx / stride), o = (uint32_t)(idx % stride);
+        uint32_t e = o;
+        if (o < 32u * nb) {
+            const uint32_t t = o >> 5, r = o & 31u, j = r >> 2, c = r & 3u;
+            e = (t << 5) + (c << 3) + j;
+        }
+        out[idx] = e < dim ? in[(size_t)row * dim + e] : 0.0f;
+    }
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, size_t n, uint32_t v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+// UpperNode::from_zero for a whole layer, core/lib.rs:323-328, core/types.rs:66-70
+__global__ void snapshot_kernel(const uint32_t* __restrict__ zero, uint32_t* __restrict__ upper_rows, uint32_t rows) {
+    const size_t total = (size_t)rows * kM;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / kM, c = i % kM;
+        upper_rows[i] = zero[r * kM2 + c];
+    }
+}
+
+// Reference invariants of an adjacency array: ids < limit, no duplicate before the
+// first INVALID (Visited makes duplicates impossible in the reference builder).
+__global__ __launch_bounds__(64) void validate_rows_kernel(const uint32_t* __restrict__ rows, uint32_t n_rows,
+                                                          int row_stride, uint32_t limit, uint32_t* bad) {
+    const int lane = lane_id();
+    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        uint32_t id = kInvalid;
+        if (lane < row_stride) id = rows[(size_t)r * row_stride + lane];
+        const uint64_t inval = __ballot(id == kInvalid);
+        const int nvalid = inval ? __builtin_ctzll(inval) : 64;
+        bool err = lane < nvalid && id >= limit;
+        for (int s = 1; s < 64; s++) {
+            const int o = (lane + s) & 63;
+            const uint32_t other = bcast_u32(id, o);
+            if (lane < nvalid && o < nvalid && other == id) err = true;
+        }
+        if (__ballot(err) && lane == 0) atomicAdd(bad, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LDS carve-up shared by the kernels.
+// ---------------------------------------------------------------------------
+struct Smem {
+    float* q;            // stride floats
+    float* cq;           // stride floats (build only)
+    uint64_t* W;         // wcap
+    uint64_t* aux;       // 3*64+1 u64 (build only): news / sel / disc
+    uint32_t* act_pid;   // 64
+    uint32_t* act_dist;  // 64
+};
+__host__ __device__ inline size_t smem_bytes(uint32_t stride, uint32_t wcap, bool build) {
+    size_t b = (size_t)stride * 4 * (build ? 2 : 1) + (size_t)wcap * 8 + 2 * 64 * 4;
+    if (build) b += (size_t)(3 * 64 + 8) * 8;
+    return b;
+}
+__device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t wcap, bool build) {
+    Smem s;
+    s.q = reinterpret_cast<float*>(base);
+    base += (size_t)stride * 4;
+    s.cq = reinterpret_cast<float*>(base);
+    if (build) base += (size_t)stride * 4;
+    s.W = reinterpret_cast<uint64_t*>(base);
+    base += (size_t)wcap * 8;
+    s.aux = reinterpret_cast<uint64_t*>(base);
+    if (build) base += (size_t)(3 * 64 + 8) * 8;
+    s.act_pid = reinterpret_cast<uint32_t*>(base);
+    s.act_dist = s.act_pid + 64;
+    return s;
+}
+
+// ---------------------------------------------------------------------------
+// Hnsw::search (core/lib.rs:352-383) for a batch: persistent slots pull queries.
+// ---------------------------------------------------------------------------
+struct SearchArgs {
+    const float* queries;   // [nq][dim] natural order, device
+    uint32_t nq, ef, wcap;
+    uint32_t* out_pid;      // [nq][ef]
+    float* out_dist;        // [nq][ef]
+    uint32_t* out_count;    // [nq]
+    uint32_t* out_counters; // [nq][3] or null
+    uint8_t* visited;       // [slots][vis_stride]
+    size_t vis_stride;
+    uint8_t* gen;           // [slots]
+    uint32_t* next;         // work queue head
+    uint32_t* status;
+};
+
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) {
+    IDIST_DYN_SMEM(smem_raw);
+    const Smem sm = carve(smem_raw, ix.stride, a.wcap, false);
+    const int lane = lane_id();
+    const uint32_t slot = blockIdx.x;
+    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot]};
+    uint32_t status = 0;
+    const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
+    for (;;) {
+        uint32_t qi = 0;
+        if (lane == 0) qi = atomicAdd(a.next, 1u);
+        qi = uniform_u32(qi);
+        if (qi >= a.nq) break;
+
+        // stage the query tile in LDS in the blocked order of the point rows
+        for (uint32_t o = lane; o < ix.stride; o += 64) sm.q[o] = 0.0f;
+        wave_sync();
+        const float* qsrc = a.queries + (size_t)qi * ix.dim;
+        for (uint32_t e = lane; e < ix.dim; e += 64) sm.q[blocked_pos(e, nb)] = qsrc[e];
+        wave_sync();
+
+        WState st{sm.W, 0, 1, 0, 0u};
+        Counters ctr{0, 0, 0};
+        visited_clear(vis);                                            // search.reset(), :357
+        push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr);  // :364
+        for (int cur = (int)ix.n_upper;; cur--) {                      // :365
+            const bool is_zero = cur == 0;
+            st.ef = is_zero ? (int)a.ef : 1;                           // :366-371
+            if (is_zero) {
+                search_layer<NB, RS, TAIL>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true);
+                break;
+            }
+            const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
+            search_layer<NB, RS, TAIL>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false);
+            w_cull(st);                                                // :377-379
+            visited_clear(vis);
+            for (int i = lane; i < st.plen; i += 64) vis.store[(uint32_t)st.W[i]] = (uint8_t)vis.gen;
+            wave_sync();
+        }
+        const int cnt = st.plen < st.ef ? st.plen : st.ef;             // search.iter(), :382
+        for (uint32_t i = lane; i < a.ef; i += 64) {
+            uint32_t pid = kInvalid;
+            float d = __uint_as_float(0x7f800000u);
+            if ((int)i < cnt) {
+                const uint64_t k = st.W[i] & kKeyMask;
+                pid = (uint32_t)k;
+                d = __uint_as_float((uint32_t)(k >> 32));
+            }
+            a.out_pid[(size_t)qi * a.ef + i] = pid;
+            a.out_dist[(size_t)qi * a.ef + i] = d;
+        }
+        if (lane == 0) {
+            a.out_count[qi] = (uint32_t)cnt;
+            if (a.out_counters) {
+                a.out_counters[3 * (size_t)qi + 0] = ctr.n_dist;
+                a.out_counters[3 * (size_t)qi + 1] = ctr.n_exp0;
+                a.out_counters[3 * (size_t)qi + 2] = ctr.n_expU;
+            }
+        }
+        status |= st.status;
+        wave_sync();
+    }
+    if (lane == 0) {
+        a.gen[slot] = (uint8_t)vis.gen;
+        if (status) atomicOr(a.status, status);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Point::distance over id lists (the gather-L2 kernel on its own).
+// grid = nq * ceil(n_ids/64) waves.
+// ---------------------------------------------------------------------------
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(64) void distance_batch_kernel(IndexView ix, const float* __restrict__ queries, uint32_t nq,
+                                                           const uint32_t* __restrict__ ids, uint32_t n_ids,
+                                                           float* __restrict__ out) {
+    IDIST_DYN_SMEM(smem_raw);
+    const Smem sm = carve(smem_raw, ix.stride, 0, false);
+    const int lane = lane_id();
+    const uint32_t chunks = (n_ids + 63u) / 64u;
+    const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
+    for (uint32_t w = blockIdx.x; w < nq * chunks; w += gridDim.x) {
+        const uint32_t qi = w / chunks, c0 = (w % chunks) * 64u;
+        wave_sync();
+        for (uint32_t o = lane; o < ix.stride; o += 64) sm.q[o] = 0.0f;
+        wave_sync();
+        for (uint32_t e = lane; e < ix.dim; e += 64) sm.q[blocked_pos(e, nb)] = queries[(size_t)qi * ix.dim + e];
+        const uint32_t i = c0 + lane;
+        uint32_t id = kInvalid;
+        if (i < n_ids) id = ids[(size_t)qi * n_ids + i];
+        const bool ok = id != kInvalid && id < ix.n;
+        const uint64_t m = __ballot(ok);
+        const int my = __popcll(m & ((1ull << lane) - 1ull));
+        if (ok) sm.act_pid[my] = id;
+        wave_sync();
+        dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, __popcll(m));
+        wave_sync();
+        if (i < n_ids) out[(size_t)qi * n_ids + i] = ok ? __uint_as_float(sm.act_dist[my]) : __uint_as_float(0x7f800000u);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Exhaustive exact top-k with the canonical distance (ground truth; the brute
+// force of tests/all.rs:60-67).  One wave per query, W machinery with ef = k.
+// ---------------------------------------------------------------------------
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(64) void bruteforce_kernel(IndexView ix, const float* __restrict__ queries, uint32_t nq,
+                                                       uint32_t k, uint32_t wcap, uint32_t* out_pid, float* out_dist,
+                                                       uint32_t* next) {
+    IDIST_DYN_SMEM(smem_raw);
+    const Smem sm = carve(smem_raw, ix.stride, wcap, false);
+    const int lane = lane_id();
+    const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
+    for (;;) {
+        uint32_t qi = 0;
+        if (lane == 0) qi = atomicAdd(next, 1u);
+        qi = uniform_u32(qi);
+        if (qi >= nq) break;
+        wave_sync();
+        for (uint32_t o = lane; o < ix.stride; o += 64) sm.q[o] = 0.0f;
+        wave_sync();
+        for (uint32_t e = lane; e < ix.dim; e += 64) sm.q[blocked_pos(e, nb)] = queries[(size_t)qi * ix.dim + e];
+        wave_sync();
+        WState st{sm.W, 0, (int)k, 0, 0u};
+        for (uint32_t base = 0; base < ix.n; base += 64) {
+            const int na = ix.n - base < 64u ? (int)(ix.n - base) : 64;
+            if (lane < na) sm.act_pid[lane] = base + lane;
+            wave_sync();
+            dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, na);
+            wave_sync();
+            uint64_t key = kMaxKey;
+            if (lane < na) key = ((uint64_t)sm.act_dist[lane] << 32) | (base + lane);
+            const uint64_t thr = st.plen >= st.ef ? (st.W[st.ef - 1] & kKeyMask) : kMaxKey + 1ull;
+            uint64_t pm = __ballot(lane < na && key < thr);
+            while (pm) {
+                const int i = __builtin_ctzll(pm);
+                pm &= pm - 1ull;
+                const uint64_t kk = bcast_u64(key, i);
+                const int idx = w_rank(st, kk);
+                if (idx < st.ef) w_insert(st, idx, kk);
+            }
+            if (st.plen > st.ef) st.plen = st.ef;   // plain truncate (no candidates here)
+            wave_sync();
+        }
+        for (uint32_t i = lane; i < k; i += 64) {
+            uint32_t pid = kInvalid;
+            float d = __uint_as_float(0x7f800000u);
+            if ((int)i < st.plen) {
+                pid = (uint32_t)st.W[i];
+                d = __uint_as_float((uint32_t)((st.W[i] & kKeyMask) >> 32));
+            }
+            out_pid[(size_t)qi * k + i] = pid;
+            out_dist[(size_t)qi * k + i] = d;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Build step A: Construction::insert up to and including select_heuristic
+// (core/lib.rs:437-473, :516) for the pids [start, start+count) of one layer
+// range.  The graph is read-only here; the new node's own row and one edge
+// record per selected neighbour are the only writes.
+// ---------------------------------------------------------------------------
+struct BuildArgs {
+    uint32_t start, count;      // batch = pids [start, start+count)
+    uint32_t layer, top;        // LayerId of this range / of the top layer
+    uint32_t efc, wcap;
+    uint32_t keep_pruned;
+    uint8_t* visited;           // [slots][vis_stride]
+    size_t vis_stride;
+    uint8_t* gen;               // [slots]
+    uint32_t* edge_pid;         // [max_batch*64] neighbour selected by item*64+i
+    uint32_t* edge_dist;        // its distance bits
+    uint32_t* head;             // [n] inbox head per existing node (edge index), kInvalid = empty
+    uint32_t* next;             // [max_batch*64] inbox links
+    uint32_t* touched;          // distinct nodes with a non-empty inbox
+    uint32_t* n_touched;
+    uint32_t* queue;            // work queue heads: [0] step A, [1] step B
+    unsigned long long* stats;  // [8] n_dist n_exp0 n_expU n_heur_dist n_heur_rows n_updates
+    uint32_t* status;
+};
+
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArgs a) {
+    IDIST_DYN_SMEM(smem_raw);
+    const Smem sm = carve(smem_raw, ix.stride, a.wcap, true);
+    uint64_t* sel = sm.aux + 64 + 8;
+    uint64_t* disc = sel + 64;
+    const int lane = lane_id();
+    const uint32_t slot = blockIdx.x;
+    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot]};
+    uint32_t status = 0;
+    Counters tot{0, 0, 0};
+    HeurCounters hc{0, 0};
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(&a.queue[0], 1u);
+        item = uniform_u32(item);
+        if (item >= a.count) break;
+        const uint32_t nw_pid = a.start + item;
+        wave_sync();
+        // point = &points[new] (:442): rows are stored blocked already
+        const float* prow = ix.points + (size_t)nw_pid * ix.stride;
+        for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+            *reinterpret_cast<float4*>(sm.q + o) = *reinterpret_cast<const float4*>(prow + o);
+        wave_sync();
+
+        WState st{sm.W, 0, 1, 0, 0u};
+        visited_clear(vis);                                           // search.reset(), :443
+        push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot);  // :444
+        const int num = a.layer == 0 ? kM2 : kM;                      // :445
+        for (int cur = (int)a.top;; cur--) {                          // :447
+            st.ef = cur <= (int)a.layer ? (int)a.efc : 1;             // :448-452
+            if (cur > (int)a.layer) {                                 // :453-457
+                const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
+                search_layer<NB, RS, TAIL>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false);
+                w_cull(st);
+                visited_clear(vis);
+                for (int i = lane; i < st.plen; i += 64) vis.store[(uint32_t)st.W[i]] = (uint8_t)vis.gen;
+                wave_sync();
+            } else {                                                  // :458-461
+                search_layer<NB, RS, TAIL>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0);
+                break;
+            }
+        }
+        const int nw = st.plen < st.ef ? st.plen : st.ef;             // Search.nearest
+        const int nsel = select_heuristic<NB, RS, TAIL>(ix, st.W, nw, a.keep_pruned != 0, sm.cq, sel, disc,
+                                                        sm.act_pid, sm.act_dist, hc);  // :470-472
+        // node.set(i, pid) for every found neighbour (:516); the row was all-INVALID
+        ix.zero[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
+        if (lane < nsel) {
+            const uint64_t k = sel[lane];
+            const uint32_t e = item * kM2 + (uint32_t)lane;
+            const uint32_t pid = (uint32_t)k;
+            a.edge_pid[e] = pid;
+            a.edge_dist[e] = (uint32_t)(k >> 32);
+            const uint32_t old = atomicExch(&a.head[pid], e);
+            a.next[e] = old;
+            if (old == kInvalid) a.touched[atomicAdd(a.n_touched, 1u)] = pid;
+        }
+        status |= st.status;
+        wave_sync();
+    }
+    if (lane == 0) {
+        a.gen[slot] = (uint8_t)vis.gen;
+        if (status) atomicOr(a.status, status);
+        if (tot.n_dist | tot.n_exp0 | tot.n_expU | hc.n_rows) {
+            atomicAdd(&a.stats[0], (unsigned long long)tot.n_dist);
+            atomicAdd(&a.stats[1], (unsigned long long)tot.n_exp0);
+            atomicAdd(&a.stats[2], (unsigned long long)tot.n_expU);
+            atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
+            atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Build step B: for every node that was selected by at least one new point,
+// Search::add_neighbor_heuristic + ZeroNode::rewrite (core/lib.rs:485-496,
+// :616-631; core/types.rs:88-98).  With one new point per step this is the
+// reference's loop body verbatim; with several, all new points that chose the
+// node are pushed (nearest first) before its single re-selection.
+// ---------------------------------------------------------------------------
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArgs a) {
+    IDIST_DYN_SMEM(smem_raw);
+    const Smem sm = carve(smem_raw, ix.stride, a.wcap, true);
+    uint64_t* news = sm.aux;            // 64 + 8 (sorted, nearest first)
+    uint64_t* sel = sm.aux + 64 + 8;
+    uint64_t* disc = sel + 64;
+    const int lane = lane_id();
+    const uint32_t ntouched = *a.n_touched;
+    HeurCounters hc{0, 0};
+    uint32_t updates = 0, status = 0;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&a.queue[1], 1u);
+        t = uniform_u32(t);
+        if (t >= ntouched) break;
+        const uint32_t pid = a.touched[t];
+        wave_sync();
+        // drain the inbox: keep the <= 64 nearest new points (a node holds 64 links at most)
+        WState ns{news, 0, kM2, 0, 0u};
+        uint32_t e = a.head[pid];
+        uint32_t guard = 0;
+        while (e != kInvalid) {
+            const uint64_t k = ((uint64_t)a.edge_dist[e] << 32) | (a.start + e / kM2);
+            const int idx = w_rank(ns, k);
+            if (idx < ns.ef) w_insert(ns, idx, k);
+            if (ns.plen > ns.ef) ns.plen = ns.ef;
+            e = a.next[e];
+            if (++guard > a.count) { status |= kStGuard; break; }
+        }
+        if (lane == 0) a.head[pid] = kInvalid;
+
+        // point = &points[pid] (:489)
+        const float* prow = ix.points + (size_t)pid * ix.stride;
+        for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+            *reinterpret_cast<float4*>(sm.q + o) = *reinterpret_cast<const float4*>(prow + o);
+        // current = zero.nearest_iter(pid) (:487): all valid slots of the 64
+        const uint32_t cur = ix.zero[(size_t)pid * kM2 + lane];
+        const uint64_t inval = __ballot(cur == kInvalid);
+        const int ncur = inval ? __builtin_ctzll(inval) : 64;
+        if (lane < ncur) sm.act_pid[lane] = cur;
+        wave_sync();
+        dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, ncur);
+        wave_sync();
+        hc.n_dist += (uint32_t)ncur;
+        uint64_t key = kMaxKey;
+        if (lane < ncur) key = ((uint64_t)sm.act_dist[lane] << 32) | cur;
+
+        // insertion.reset(); push(new); push(current...) with ef = ef_construction (:440, :625-629)
+        WState st{sm.W, 0, (int)a.efc, 0, 0u};
+        for (int i = 0; i < ns.plen; i++) {
+            const uint64_t k = news[i] & kKeyMask;
+            const int idx = w_rank(st, k);
+            if (idx < st.ef) w_insert(st, idx, k);
+        }
+        for (int i = 0; i < ncur; i++) {
+            const uint64_t k = bcast_u64(key, i);
+            const int idx = w_rank(st, k);
+            if (idx < st.ef) w_insert(st, idx, k);
+        }
+        // select_heuristic over ALL of `nearest` (no truncate in add_neighbor_heuristic, :630)
+        const int nsel = select_heuristic<NB, RS, TAIL>(ix, st.W, st.plen, a.keep_pruned != 0, sm.cq, sel, disc,
+                                                        sm.act_pid, sm.act_dist, hc);
+        // ZeroNode::rewrite (core/types.rs:88-98): rows are prefix-valid, so clearing to the end is identical
+        ix.zero[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
+        updates++;
+        wave_sync();
+    }
+    if (lane == 0) {
+        if (status) atomicOr(a.status, status);
+        if (updates) {
+            atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
+            atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);
+            atomicAdd(&a.stats[5], (unsigned long long)updates);
+        }
+    }
+}
+
+}  // namespace idist

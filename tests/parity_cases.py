@@ -1,0 +1,144 @@
+"""Parity cases shared by the CPU (emulated-kernel) and GPU (-m gpu) test modules.
+
+Every case calls the product through the C ABI (include/idist.h, via the ctypes host
+layer) and checks it against the CPU oracle on the same seeded inputs.  Bit-exact for
+ids/order/counts/counters; distances compared as raw f32 bits.
+"""
+import numpy as np
+
+INVALID = 0xFFFFFFFF
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def gen_points(rng, n, dim, kind="uniform"):
+    if kind == "uniform":        # what the reference's tests use (tests/all.rs:59, test.py:5)
+        return rng.random((n, dim), dtype=np.float32)
+    if kind == "grid":           # integer coordinates: exact ties in the distance (examples/colors.rs style)
+        return rng.integers(0, 6, size=(n, dim)).astype(np.float32)
+    if kind == "lowrank":        # fastText-shape: low intrinsic dimension, normalised rows
+        z = rng.standard_normal((n, 8)).astype(np.float32)
+        a = rng.standard_normal((8, dim)).astype(np.float32)
+        x = z @ a + 0.05 * rng.standard_normal((n, dim)).astype(np.float32)
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    raise ValueError(kind)
+
+
+def check_distance_batch(ida, oracle, n, dim, metric, seed=0, nq=5, n_ids=70):
+    rng = np.random.default_rng(seed)
+    pts = gen_points(rng, n, dim)
+    b = ida.Builder().metric(metric).max_batch(1)
+    # an index with an empty graph is enough for the gather-L2 kernel
+    zero = np.full((n, 64), INVALID, dtype=np.uint32)
+    h = ida.Hnsw.from_parts(pts, zero, [], b)
+    q = gen_points(rng, nq, dim)
+    ids = rng.integers(0, n, size=(nq, n_ids)).astype(np.uint32)
+    ids[0, 3] = INVALID
+    ids[-1, -1] = INVALID
+    got = h.distances(q, ids)
+    want = np.array([[oracle.distance(q[i], pts[j], metric) if j != INVALID else np.inf for j in ids[i]]
+                     for i in range(nq)], dtype=np.float32)
+    assert np.array_equal(bits(got), bits(want))
+
+
+_ORACLE_CACHE = {}
+
+
+def oracle_graph(oracle, n, dim, kind, metric, seed, threads, ef_construction):
+    """Oracle-built graph, cached per parameter set (the oracle build dominates test time)."""
+    key = (n, dim, kind, metric, seed, threads, ef_construction)
+    if key not in _ORACLE_CACHE:
+        rng = np.random.default_rng(seed)
+        pts = gen_points(rng, n, dim, kind)
+        cfg = oracle.default_config(metric=metric, ef_construction=ef_construction)
+        _ORACLE_CACHE.clear()            # keep at most one graph alive
+        _ORACLE_CACHE[key] = (pts, oracle.Index.build(pts, cfg, threads=threads), rng)
+    return _ORACLE_CACHE[key]
+
+
+def check_search_parity(ida, oracle, n, dim, ef_search=100, metric=0, kind="uniform", nq=16, seed=0, threads=1,
+                        ef_construction=100, graph_seed=None):
+    """Oracle builds the graph; engine imports it; same queries must give identical results."""
+    pts, oix, _ = oracle_graph(oracle, n, dim, kind, metric, seed if graph_seed is None else graph_seed, threads,
+                               ef_construction)
+    oix.set_ef_search(ef_search)
+    rng = np.random.default_rng(seed + 1000003)
+    b = ida.Builder().metric(metric).ef_search(ef_search)
+    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, b)
+    q = gen_points(rng, nq, dim, kind)
+    if kind == "uniform" and nq > 2:
+        q[1] = pts[min(5, n - 1)]          # a stored point: distance 0 first (test.py:15-35)
+    got = h.search_batch(q, ida.Search(), counters=True)
+    want = oix.search(q, threads=1)
+    assert np.array_equal(got.count, want.count)
+    assert np.array_equal(got.pid, want.pid)
+    assert np.array_equal(bits(got.distance), bits(want.dist))
+    assert np.array_equal(got.counters, want.counters)
+    # sortedness + idempotence (size independent properties)
+    for i in range(nq):
+        c = int(got.count[i])
+        d = got.distance[i, :c]
+        assert np.all(d[:-1] <= d[1:])
+        assert len(set(got.pid[i, :c].tolist())) == c
+    again = h.search_batch(q, ida.Search())
+    assert np.array_equal(again.pid, got.pid)
+    return h, oix
+
+
+def check_build_exact(ida, oracle, n, dim, metric=0, kind="uniform", ef_construction=100, keep_pruned=True, seed=0):
+    """max_batch = 1: zero/layers byte-identical to the oracle's sequential build."""
+    rng = np.random.default_rng(seed)
+    pts = gen_points(rng, n, dim, kind)
+    cfg = oracle.default_config(metric=metric, ef_construction=ef_construction, keep_pruned=int(keep_pruned))
+    oix = oracle.Index.build(pts, cfg, threads=1)
+    b = (ida.Builder().metric(metric).max_batch(1).ef_construction(ef_construction)
+         .select_heuristic(ida.Heuristic(False, keep_pruned)))
+    h = ida.Hnsw.from_ordered_points(pts, b)
+    zero, layers = h.into_parts()
+    assert np.array_equal(zero, oix.zero)
+    assert len(layers) == len(oix.layers)
+    for a, o in zip(layers, oix.layers):
+        assert np.array_equal(a, o)
+    st = h.build_stats()
+    assert st.n_dist == oix.build_counters.n_dist
+    assert st.n_exp0 == oix.build_counters.n_exp0 and st.n_expU == oix.build_counters.n_expU
+    return h
+
+
+def recall_at(found_pid, truth_pid, k):
+    hit = 0
+    for f, t in zip(found_pid, truth_pid):
+        hit += len(set(f[:k].tolist()) & set(t[:k].tolist()))
+    return hit / (k * len(truth_pid))
+
+
+def check_build_batched(ida, oracle, n, dim, max_batch=0, kind="uniform", k=10, nq=50, seed=0, min_recall=0.95):
+    """Concurrent inserts (the rayon path, core/lib.rs:316-318): judged by recall + degree."""
+    rng = np.random.default_rng(seed)
+    pts = gen_points(rng, n, dim, kind)
+    q = gen_points(rng, nq, dim, kind)
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder().max_batch(max_batch))
+    truth, _ = h.bruteforce(q, k)
+    o_truth, _ = oracle.bruteforce(pts, q, k)
+    assert np.array_equal(truth, o_truth)
+    got = h.search_batch(q, ida.Search())
+    rec = recall_at(got.pid, truth, k)
+    assert rec >= min_recall, rec
+    zero, layers = h.into_parts()
+    # graph invariants of the reference builder
+    assert zero.shape == (n, 64)
+    valid = zero != INVALID
+    assert np.all(valid[:, :-1] >= valid[:, 1:])                       # prefix-valid rows
+    assert np.all(zero[valid] < n)
+    for r in range(0, n, max(1, n // 50)):
+        ids = zero[r][valid[r]]
+        assert len(set(ids.tolist())) == len(ids) and r not in ids    # unique, no self loop
+    sizes = oracle.layer_sizes(n)
+    assert [l.shape[0] for l in layers] == sizes[1:]
+    # deterministic given the batch schedule
+    h2 = ida.Hnsw.from_ordered_points(pts, ida.Builder().max_batch(max_batch))
+    z2, l2 = h2.into_parts()
+    assert np.array_equal(zero, z2)
+    return rec

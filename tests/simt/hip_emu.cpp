@@ -1,0 +1,146 @@
+// hip_emu.cpp — scheduler of the CPU lockstep emulator (TEST INFRASTRUCTURE, see hip_emu.hpp).
+#include "hip_emu.hpp"
+
+namespace emu {
+
+State& S() {
+    static State s;
+    return s;
+}
+
+// void idist_emu_switch(void** save_sp, void* new_sp): save callee-saved registers, swap stacks
+asm(R"(
+.text
+.globl idist_emu_switch
+.type idist_emu_switch,@function
+idist_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size idist_emu_switch, .-idist_emu_switch
+)");
+
+static void lane_entry() {
+    State& s = S();
+    (*s.body)();
+    s.cur->alive = false;
+    yield_to_sched();
+    abort();  // a dead lane is never resumed
+}
+
+static constexpr size_t kStack = 256 * 1024;
+
+static void init_lane(Lane& l, uint32_t tid) {
+    if (!l.stack) {
+        void* m = nullptr;
+        if (posix_memalign(&m, 64, kStack)) abort();
+        l.stack = (uint8_t*)m;
+    }
+    uintptr_t top = ((uintptr_t)l.stack + kStack) & ~(uintptr_t)15;
+    uint64_t* sp = (uint64_t*)top;
+    *--sp = 0;                        // fake return address of lane_entry
+    *--sp = (uint64_t)&lane_entry;    // `ret` target
+    for (int i = 0; i < 6; i++) *--sp = 0;  // rbp rbx r12 r13 r14 r15
+    l.sp = sp;
+    l.tid = Dim3{tid, 0, 0};
+    l.alive = true;
+    l.waiting = false;
+    l.op = OP_NONE;
+}
+
+static const char* op_name(int op) {
+    switch (op) {
+        case OP_SYNC: return "__syncthreads";
+        case OP_BALLOT: return "__ballot";
+        case OP_SHFL: return "__shfl";
+        case OP_SHFL_XOR: return "__shfl_xor";
+        case OP_READFIRST: return "readfirstlane";
+        default: return "none";
+    }
+}
+
+void launch(uint32_t grid, uint32_t block, size_t smem_bytes, const std::function<void()>& body) {
+    State& s = S();
+    const char* ord = getenv("IDIST_EMU_ORDER");
+    s.reverse = ord && ord[0] == 'r';
+    if (s.lanes.size() < block) s.lanes.resize(block);
+    void* sm = nullptr;
+    if (posix_memalign(&sm, 256, smem_bytes + 256)) abort();
+    s.smem = (uint8_t*)sm;
+    s.body = &body;
+    s.bdim = Dim3{block, 1, 1};
+    s.gdim = Dim3{grid, 1, 1};
+    for (uint32_t b = 0; b < grid; b++) {
+        s.blk = Dim3{b, 0, 0};
+        memset(s.smem, 0xCD, smem_bytes + 256);
+        for (uint32_t i = 0; i < block; i++) init_lane(s.lanes[i], i);
+        for (;;) {
+            for (uint32_t k = 0; k < block; k++) {
+                Lane& l = s.lanes[s.reverse ? block - 1 - k : k];
+                if (l.alive && !l.waiting) {
+                    s.cur = &l;
+                    idist_emu_switch(&s.sched_sp, l.sp);
+                }
+            }
+            // every live lane now waits at a collective
+            int op = OP_NONE;
+            uint32_t n_alive = 0, first = block;
+            for (uint32_t i = 0; i < block; i++) {
+                Lane& l = s.lanes[i];
+                if (!l.alive) continue;
+                if (first == block) first = i;
+                n_alive++;
+                if (op == OP_NONE) op = l.op;
+                else if (op != l.op) {
+                    fprintf(stderr, "[hip_emu] DIVERGENT COLLECTIVE in block %u: lane %u at %s, lane %u at %s\n", b, first,
+                            op_name(op), i, op_name(l.op));
+                    abort();
+                }
+            }
+            if (!n_alive) break;
+            if (n_alive != block && op != OP_SYNC && getenv("IDIST_EMU_STRICT")) {
+                fprintf(stderr, "[hip_emu] collective %s with %u/%u lanes alive\n", op_name(op), n_alive, block);
+                abort();
+            }
+            if (op != OP_SYNC && block > 64) {
+                fprintf(stderr, "[hip_emu] wave collective in a %u-thread block is not modelled\n", block);
+                abort();
+            }
+            s.n_collectives++;
+            uint64_t ballot = 0;
+            if (op == OP_BALLOT)
+                for (uint32_t i = 0; i < block; i++)
+                    if (s.lanes[i].alive && s.lanes[i].val) ballot |= 1ull << i;
+            for (uint32_t i = 0; i < block; i++) {
+                Lane& l = s.lanes[i];
+                if (!l.alive) continue;
+                switch (op) {
+                    case OP_SYNC: l.res = 0; break;
+                    case OP_BALLOT: l.res = ballot; break;
+                    case OP_SHFL: { const Lane& o = s.lanes[(uint32_t)l.arg % block]; l.res = o.alive ? o.val : 0; break; }
+                    case OP_SHFL_XOR: { const uint32_t j = i ^ (uint32_t)l.arg; l.res = (j < block && s.lanes[j].alive) ? s.lanes[j].val : l.val; break; }
+                    case OP_READFIRST: l.res = s.lanes[first].val; break;
+                    default: break;
+                }
+            }
+            for (uint32_t i = 0; i < block; i++) s.lanes[i].waiting = false;
+        }
+    }
+    free(sm);
+    s.smem = nullptr;
+    s.body = nullptr;
+}
+
+}  // namespace emu

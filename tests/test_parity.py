@@ -1,0 +1,191 @@
+"""HIP path vs CPU oracle through the C ABI (include/idist.h).
+
+CPU (`-m "not gpu"`): the real kernel source under the lockstep emulator, tiny sizes.
+GPU (`-m gpu`): libidist.so on the MI355X at the sizes the oracle finishes in seconds.
+Bar: ids / order / counts / work counters bit-exact, distances equal as raw f32 bits.
+"""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from engines import engine_params
+
+
+@pytest.fixture(params=engine_params())
+def eng(request, engine_loader):
+    ida = engine_loader(request.param)
+    return ida, request.param
+
+
+def S(kind, emu, gpu):
+    return gpu if kind == "gpu" else emu
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3, 4, 7, 13, 32, 100, 128, 300, 301, 768])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_distance_batch(eng, oracle, dim, metric):
+    ida, kind = eng
+    pc.check_distance_batch(ida, oracle, n=S(kind, 40, 3000), dim=dim, metric=metric, seed=dim,
+                            nq=S(kind, 3, 9), n_ids=S(kind, 70, 200))
+
+
+@pytest.mark.parametrize("dim,kind_", [(2, "uniform"), (16, "uniform"), (128, "uniform"), (300, "uniform"),
+                                       (300, "lowrank"), (768, "uniform"), (3, "grid"), (2, "grid")])
+def test_search_parity(eng, oracle, dim, kind_):
+    ida, kind = eng
+    n = S(kind, 260, {2: 20000, 3: 20000, 16: 20000, 128: 12000, 300: 8000, 768: 3000}[dim])
+    metric = 1 if kind_ == "grid" else 0
+    pc.check_search_parity(ida, oracle, n=n, dim=dim, kind=kind_, metric=metric, nq=S(kind, 6, 400), seed=dim)
+
+
+@pytest.mark.parametrize("ef", [1, 2, 10, 64, 100, 150, 500])
+def test_search_parity_ef_sweep(eng, oracle, ef):
+    ida, kind = eng
+    pc.check_search_parity(ida, oracle, n=S(kind, 300, 20000), dim=S(kind, 8, 128), ef_search=ef,
+                           nq=S(kind, 5, 300), seed=ef, graph_seed=77)
+
+
+def test_search_parity_heavy_ties(eng, oracle):
+    # few distinct coordinates => many exactly equal distances: exercises the distance-only
+    # break test (core/lib.rs:600-604) and the (distance, pid) tie-break (core/types.rs:229-234)
+    ida, kind = eng
+    rng = np.random.default_rng(3)
+    n = S(kind, 250, 5000)
+    pts = rng.integers(0, 3, size=(n, 4)).astype(np.float32)
+    cfg = oracle.default_config(metric=1, ef_search=20)
+    oix = oracle.Index.build(pts, cfg)
+    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().metric(1).ef_search(20))
+    q = rng.integers(0, 3, size=(S(kind, 8, 200), 4)).astype(np.float32)
+    try:
+        got = h.search_batch(q, ida.Search(), counters=True)
+    except ida.IdistError as e:          # > 64 live equidistant candidates is reported, never silent
+        assert e.status == 6
+        return
+    want = oix.search(q)
+    assert np.array_equal(got.pid, want.pid) and np.array_equal(got.counters, want.counters)
+    assert np.array_equal(pc.bits(got.distance), pc.bits(want.dist))
+
+
+def test_search_on_parallel_built_graph(eng, oracle):
+    # graphs from the rayon-style build (core/lib.rs:316-318) are not distance-sorted per row
+    ida, kind = eng
+    pc.check_search_parity(ida, oracle, n=S(kind, 300, 20000), dim=S(kind, 6, 64), threads=4, nq=S(kind, 5, 200), seed=9)
+
+
+@pytest.mark.parametrize("n,dim,kw", [
+    (1, 4, {}), (2, 4, {}), (5, 2, {"metric": 1}), (33, 3, {}), (100, 2, {"metric": 1}),
+    (150, 12, {}), (120, 300, {}), (140, 8, {"ef_construction": 20}), (130, 5, {"keep_pruned": False}),
+    (140, 3, {"kind": "grid", "metric": 1}),
+])
+def test_build_exact_small(eng, oracle, n, dim, kw):
+    ida, kind = eng
+    pc.check_build_exact(ida, oracle, n=n, dim=dim, seed=n, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dim", [(1024, 2), (3000, 128), (2000, 300), (1200, 768)])
+def test_build_exact_gpu(engine_loader, oracle, n, dim):
+    ida = engine_loader("gpu")
+    pc.check_build_exact(ida, oracle, n=n, dim=dim, seed=n)
+
+
+def test_build_batched(eng, oracle):
+    ida, kind = eng
+    rec = pc.check_build_batched(ida, oracle, n=S(kind, 220, 30000), dim=S(kind, 4, 32), max_batch=S(kind, 4, 0),
+                                 nq=S(kind, 20, 500))
+    assert rec >= 0.95
+
+
+@pytest.mark.gpu
+def test_build_batched_matches_oracle_recall_gpu(engine_loader, oracle):
+    """throughput-mode tier: recall@10 within noise of the oracle's parallel build."""
+    ida = engine_loader("gpu")
+    rng = np.random.default_rng(0)
+    n, dim = 50000, 64
+    pts = pc.gen_points(rng, n, dim, "lowrank")
+    q = pc.gen_points(rng, 1000, dim, "lowrank")
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder())
+    truth, _ = h.bruteforce(q, 10)
+    got = h.search_batch(q, ida.Search())
+    rec_gpu = pc.recall_at(got.pid, truth, 10)
+    oix = oracle.Index.build(pts, oracle.default_config(), threads=8)
+    rec_cpu = pc.recall_at(oix.search(q, threads=8).pid, truth, 10)
+    assert rec_gpu >= rec_cpu - 0.02, (rec_gpu, rec_cpu)
+    dz = (h.into_parts()[0] != pc.INVALID).sum(1).mean()
+    do = (oix.zero != pc.INVALID).sum(1).mean()
+    assert abs(dz - do) < 4, (dz, do)
+
+
+def test_bruteforce(eng, oracle):
+    ida, kind = eng
+    rng = np.random.default_rng(1)
+    n, dim = S(kind, 200, 20000), S(kind, 10, 300)
+    pts = pc.gen_points(rng, n, dim)
+    q = pc.gen_points(rng, S(kind, 4, 64), dim)
+    h = ida.Hnsw.from_parts(pts, np.full((n, 64), pc.INVALID, np.uint32), [], ida.Builder())
+    pid, dist = h.bruteforce(q, 10)
+    opid, odist = oracle.bruteforce(pts, q, 10, threads=4)
+    assert np.array_equal(pid, opid) and np.array_equal(pc.bits(dist), pc.bits(odist))
+
+
+def test_edge_cases(eng, oracle):
+    ida, kind = eng
+    s = ida.Search()
+    # empty index (core/lib.rs:224-234, 359-361)
+    h, ids = ida.Builder().build_hnsw(np.zeros((0, 4), np.float32))
+    assert ids == [] and len(list(h.search(np.zeros(4, np.float32), s))) == 0
+    # single point: only the entry point, never inserted (core/lib.rs:279-280)
+    h, ids = ida.Builder().build_hnsw(np.ones((1, 4), np.float32))
+    items = list(h.search(np.zeros(4, np.float32), s))
+    assert ids == [0] and len(items) == 1 and items[0].pid == 0 and items[0].distance == 4.0
+    # fewer points than ef_search: every point comes back once, sorted
+    pts = np.random.default_rng(0).random((20, 3), dtype=np.float32)
+    h, ids = ida.Builder().seed(1).build_hnsw(pts)
+    items = list(h.search(pts[0], s))
+    assert len(items) == 20 and items[0].distance == 0.0 and items[0].pid == ids[0]
+    # no queries / ef_search = 0
+    assert h.search_batch(np.zeros((0, 3), np.float32), s).pid.shape == (0, 100)
+    h.set_ef_search(0)
+    assert h.search_batch(pts[:2], s).count.tolist() == [0, 0]
+    # dimension mismatch is an error, not UB
+    with pytest.raises(TypeError):
+        h.search_batch(np.zeros((1, 5), np.float32), s)
+    # values shorter than points: the reference panics (core/lib.rs:148)
+    with pytest.raises(IndexError):
+        ida.Builder().build(pts, ["a"])
+
+
+def test_import_validation_and_unsupported(eng, oracle):
+    ida, kind = eng
+    pts = np.random.default_rng(0).random((50, 4), dtype=np.float32)
+    zero = np.full((50, 64), pc.INVALID, np.uint32)
+    zero[3, 0] = 7
+    zero[3, 1] = 7                          # duplicate: impossible in the reference (Visited)
+    with pytest.raises(ida.IdistError) as e:
+        ida.Hnsw.from_parts(pts, zero, [], ida.Builder())
+    assert e.value.status == 5
+    zero[3, 1] = 50                         # id >= n
+    with pytest.raises(ida.IdistError) as e:
+        ida.Hnsw.from_parts(pts, zero, [], ida.Builder())
+    assert e.value.status == 5
+    zero[3, 1] = pc.INVALID
+    zero[3, 2] = 50                         # garbage after the first INVALID is never read (core/types.rs:183-187)
+    ida.Hnsw.from_parts(pts, zero, [], ida.Builder())
+    with pytest.raises(ida.IdistError) as e:
+        ida.Builder().select_heuristic(ida.Heuristic(True, True)).build_hnsw(pts)
+    assert e.value.status == 4
+    with pytest.raises(ida.IdistError) as e:
+        ida.Builder().ef_search(5000).build_hnsw(pts)
+    assert e.value.status == 1
+
+
+def test_permutation_matches_oracle_restatement(eng, oracle):
+    ida, kind = eng
+    from instant_distance_amd import _capi
+    import ctypes as C
+    for seed, n in [(0, 1), (1, 10), (123456789, 1024), (2**63 + 5, 777)]:
+        a = np.zeros(n, np.uint32); b = np.zeros(n, np.uint32)
+        _capi.lib().check(_capi.lib().idist_permutation(C.c_uint64(seed), n, _capi.u32p(a), _capi.u32p(b)))
+        oa, ob = oracle.permutation(seed, n)
+        assert np.array_equal(a, oa) and np.array_equal(b, ob)
+        assert sorted(a.tolist()) == list(range(n))
