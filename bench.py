@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py — queries/sec at recall@10 >= 0.95 on 1M x 300-d f32 (BASELINE.json config C3),
+plus index build points/sec, on N MI355X GPUs of one node.
+
+A "step" = one pass of Hnsw::search over this rank's batch of synthetic queries, inputs and
+outputs resident in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): rank 0
+builds the index, RCCL broadcasts it once over xGMI, every rank searches its own query
+shard (weak scaling: --nq queries per GPU), no collective inside the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     HBM bound: algorithmic bytes per launch (B_q = n_dist*4*D + n_exp0*256 +
+               n_expU*128 + 8*ef summed over the launch's queries, counted by the kernel itself
+               and equal to the oracle's counters by bit-exactness) / average kernel duration
+               measured with HIP events on the launch stream.
+  cpu_baseline the CPU oracle (restated reference, NOT the Rust crate) searching the SAME graph
+               on the host cores for a bounded query sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md chip table: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def synth(torch, n, dim, seed, device, latent=32):
+    """'fastText-shape' synthetic rows: z~N(0,I_32) A_{32xD} + 0.05 N(0,I_D), L2-normalised."""
+    g = torch.Generator(device=device)
+    g.manual_seed(4242)
+    a = torch.randn(latent, dim, generator=g, device=device, dtype=torch.float32)
+    g.manual_seed(seed)
+    out = torch.empty(n, dim, device=device, dtype=torch.float32)
+    step = 1 << 18
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        z = torch.randn(hi - lo, latent, generator=g, device=device, dtype=torch.float32)
+        x = z @ a + 0.05 * torch.randn(hi - lo, dim, generator=g, device=device, dtype=torch.float32)
+        out[lo:hi] = x / x.norm(dim=1, keepdim=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=300)
+    ap.add_argument("--nq", type=int, default=10_000, help="queries per GPU per step")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--ef", type=int, default=0, help="ef_search; 0 = smallest of 100/200/400/800 reaching the recall target")
+    ap.add_argument("--recall-target", type=float, default=0.95)
+    ap.add_argument("--gt-queries", type=int, default=1000, help="queries with exact ground truth (recall estimate)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="queries for the CPU baseline (0 = auto, ~15 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-batch", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: instant_distance_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import instant_distance_amd as ida
+    from instant_distance_amd import dist as idd
+
+    n, dim, nq, k = args.n, args.dim, args.nq, args.k
+    builder = ida.Builder().max_batch(args.max_batch).device(local_rank)
+
+    # ---- data + build (rank 0), replicate ----
+    build = {}
+    hnsw = None
+    d_pts = None
+    if rank == 0:
+        d_pts = synth(torch, n, dim, 123456789, dev)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        hnsw = ida.Hnsw.from_device_points(d_pts.data_ptr(), n, dim, builder)
+        t_build = time.time() - t0
+        st = hnsw.build_stats()
+        build = {"points_per_s": round(n / st.seconds, 1), "device_seconds": round(st.seconds, 3),
+                 "wall_seconds": round(t_build, 3), "ef_construction": 100, "batches": int(st.n_batches),
+                 "n_dist": int(st.n_dist), "n_heur_dist": int(st.n_heur_dist), "n_updates": int(st.n_updates),
+                 "alg_bytes": int(st.n_dist * 4 * dim + st.n_exp0 * 256 + st.n_expU * 128
+                                  + (st.n_heur_rows + st.n_heur_dist) * 4 * dim + st.n_updates * 512)}
+        build["alg_GBps"] = round(build["alg_bytes"] / st.seconds / 1e9, 1)
+    t_rep = 0.0
+    if world > 1:
+        t0 = time.time()
+        hnsw = idd.replicate_index(hnsw, builder, src=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_rep = time.time() - t0
+
+    # ---- queries: held-out draws, seed+1; rank r takes [r*nq, (r+1)*nq) of the global batch ----
+    d_q_all = synth(torch, nq * world, dim, 123456790, dev)
+    lo, hi = idd.shard_range(nq * world, rank, world)
+    d_q = d_q_all[lo:hi].contiguous()
+    search = ida.Search()
+
+    def alloc_out(ef):
+        return (torch.empty(nq, ef, dtype=torch.int32, device=dev), torch.empty(nq, ef, dtype=torch.float32, device=dev),
+                torch.empty(nq, dtype=torch.int32, device=dev), torch.empty(nq, 3, dtype=torch.int32, device=dev))
+
+    def run(ef, outs):
+        pid, dd, cnt, ctr = outs
+        hnsw.search_batch_device(search, d_q.data_ptr(), nq, pid.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
+                                 ctr.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+    # ---- ground truth (exact scan with the same canonical distance) + ef choice ----
+    gtq = min(args.gt_queries, nq)
+    truth, _ = hnsw.bruteforce(d_q[:gtq].cpu().numpy(), k)
+    sweep = {}
+    ef_list = [args.ef] if args.ef else [100, 200, 400, 800]
+    chosen, recall = None, 0.0
+    for ef in ef_list:
+        hnsw.set_ef_search(ef)
+        outs = alloc_out(ef)
+        run(ef, outs)
+        torch.cuda.synchronize()
+        search.check_status()
+        got = outs[0][:gtq, :k].cpu().numpy().astype(np.uint32)
+        rec = float(np.mean([len(set(got[i].tolist()) & set(truth[i].tolist())) / k for i in range(gtq)]))
+        sweep[str(ef)] = round(rec, 4)
+        chosen, recall = ef, rec
+        if rec >= args.recall_target:
+            break
+    if world > 1:   # every rank must time the same ef
+        t = torch.tensor([chosen], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        chosen = int(t.item())
+    hnsw.set_ef_search(chosen)
+    outs = alloc_out(chosen)
+
+    # ---- timed region ----
+    for _ in range(args.warmup):
+        run(chosen, outs)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run(chosen, outs)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    search.check_status()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = nq * world / (elapsed / args.steps)
+        kt = search.kernel_times_ms(args.steps)
+        ctr = outs[3].cpu().numpy().astype(np.int64)
+        launch_bytes = int((ctr[:, 0] * 4 * dim + ctr[:, 1] * 256 + ctr[:, 2] * 128 + 8 * chosen).sum())
+        kernel_ms = float(kt.mean())
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_r01.json")   # HBM bytes per launch from the committed PMC pass
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("search_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "kernel": "search_kernel", "kernel_ms_avg": round(kernel_ms, 3),
+                    "alg_bytes_per_launch": launch_bytes, "alg_bytes_per_query": round(launch_bytes / nq),
+                    "n_dist_per_query": round(float(ctr[:, 0].mean()), 1), "n_exp0_per_query": round(float(ctr[:, 1].mean()), 1),
+                    "n_expU_per_query": round(float(ctr[:, 2].mean()), 1)}
+
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import pyoracle as po
+            zero, layers = hnsw.into_parts()
+            pts_h = d_pts.cpu().numpy()
+            oix = po.Index.from_arrays(pts_h, zero, layers, po.default_config(ef_search=chosen))
+            cores = os.cpu_count() or 1
+            q_h = d_q.cpu().numpy()
+            # bounded sample: ~10-30 core-seconds of CPU work; best of 3 passes (thread start-up noise)
+            probe = min(nq, 8 * cores)
+            t0 = time.perf_counter(); oix.search(q_h[:probe], threads=cores); tp_ = time.perf_counter() - t0
+            core_s_per_q = tp_ * min(cores, probe) / probe
+            sample = args.cpu_sample or int(min(nq, max(probe, 20.0 / max(core_s_per_q, 1e-6))))
+            tc = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter(); ores = oix.search(q_h[:sample], threads=cores); tc = min(tc, time.perf_counter() - t0)
+            same = bool(np.array_equal(ores.pid, outs[0][:sample].cpu().numpy().astype(np.uint32)))
+            cpu = {"value": round(sample / tc, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+                   "sample": f"first {sample} of the {nq} queries, same graph, ef_search={chosen}, {cores} threads "
+                             "(C oracle = restated reference, not the Rust crate)",
+                   "seconds": round(tc, 2), "ids_identical_to_gpu": same}
+
+        out = {"metric": "queries/sec @ recall@10>=0.95, 1Mx300-d f32; index build points/sec",
+               "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"C3: {n}x{dim}-d f32 fastText-shape synthetic (32-d latent, L2-normalised), "
+                                      f"Builder::build on GPU + {nq}-query Hnsw::search batch per GPU, k={k}",
+                          "n": n, "dim": dim, "queries_per_gpu": nq, "k": k, "ef_search": chosen,
+                          "recall_at_10": round(recall, 4), "recall_target": args.recall_target,
+                          "recall_target_met": bool(recall >= args.recall_target), "recall_queries": gtq,
+                          "ef_sweep_recall": sweep, "parallelism": f"query-shard x{world}, index replicated",
+                          "replicate_seconds": round(t_rep, 3)},
+               "build": build, "roofline": roofline, "cpu_baseline": cpu}
+        if cpu:
+            out["gpu_over_cpu"] = round(value / cpu["value"], 2)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -175,6 +175,11 @@ idist_status idist_search_batch_device(const idist_index* idx, idist_search_ctx*
 idist_status idist_search_ctx_status(idist_search_ctx* ctx);
 /* HIP-event duration of the last search kernel launched through ctx, milliseconds. */
 idist_status idist_search_ctx_last_kernel_ms(idist_search_ctx* ctx, float* ms);
+/* Durations (ms) of the most recent search-kernel launches through ctx, oldest first, measured
+ * with HIP events recorded on the launch stream around each kernel (a ring of IDIST_EVENT_RING
+ * pairs; no synchronisation happens until this call).  *n_out = number written (<= cap). */
+#define IDIST_EVENT_RING 64u
+idist_status idist_search_ctx_kernel_times(idist_search_ctx* ctx, float* ms, uint32_t cap, uint32_t* n_out);
 
 /* Point::distance for id lists (core/lib.rs:780-782 as used at :709-710): out[q][i] =
  * distance(queries[q], points[ids[q][i]]) for i < n_ids; IDIST_INVALID ids give +inf.

@@ -155,6 +155,17 @@ class Search:
         except Exception:
             pass
 
+    def kernel_times_ms(self, last: int = 64) -> np.ndarray:
+        """HIP-event durations of the most recent search kernels launched through this Search."""
+        out = np.zeros(last, dtype=np.float32)
+        n = C.c_uint32(0)
+        _lib().check(_lib().idist_search_ctx_kernel_times(self._ctx, _capi.f32p(out), last, C.byref(n)))
+        return out[: n.value]
+
+    def check_status(self):
+        """Raise if a device-side guard tripped during the launches so far (after a stream sync)."""
+        _lib().check(_lib().idist_search_ctx_status(self._ctx))
+
     def __iter__(self):
         return self
 
@@ -250,6 +261,18 @@ class Hnsw:
         return cls(h, pts, builder._ef_search)
 
     @classmethod
+    def from_device_points(cls, d_points_ptr: int, n: int, dim: int, builder: Builder | None = None,
+                           host_points: np.ndarray | None = None) -> "Hnsw":
+        """Build from points already resident in HBM (row-major n x dim f32, PointId order)."""
+        builder = builder or Builder()
+        cfg = builder._config()
+        h = C.c_void_p()
+        L = _lib()
+        L.check(L.idist_index_build_device(C.c_void_p(d_points_ptr), n, dim, C.byref(cfg), builder._device, C.byref(h)))
+        pts = host_points if host_points is not None else np.zeros((n, 0), dtype=np.float32)
+        return cls(h, pts, builder._ef_search)
+
+    @classmethod
     def from_parts(cls, points_in_pid_order, zero, layers, builder: Builder | None = None) -> "Hnsw":
         """Adopt the fields of `struct Hnsw` (core/lib.rs:194-199): points, zero, layers."""
         builder = builder or Builder()
@@ -318,6 +341,15 @@ class Hnsw:
             L.check(L.idist_search_batch(self._h, ctx, _capi.f32p(q), nq, _capi.u32p(pid), _capi.f32p(dist),
                                          _capi.u32p(cnt), _capi.u32p(ctr) if counters else None))
         return BatchResult(pid, dist, cnt, ctr)
+
+    def search_batch_device(self, search: Search, d_queries: int, nq: int, d_pid: int, d_dist: int, d_count: int,
+                            d_counters: int = 0, stream: int = 0):
+        """Device-pointer variant: inputs/outputs stay in HBM, enqueued on `stream` without a sync."""
+        ctx = search._bind(self)
+        L = _lib()
+        L.check(L.idist_search_batch_device(self._h, ctx, C.c_void_p(d_queries), nq, C.c_void_p(d_pid), C.c_void_p(d_dist),
+                                            C.c_void_p(d_count), C.c_void_p(d_counters) if d_counters else None,
+                                            C.c_void_p(stream) if stream else None))
 
     def search(self, point, search: Search) -> Search:
         """Search the index for the points nearest to `point` (core/lib.rs:352-383).

@@ -163,8 +163,8 @@ struct idist_search_ctx {
     uint8_t* d_gen = nullptr;
     uint32_t* d_next = nullptr;    // [0] queue head, [1] status
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    hipEvent_t ev0[IDIST_EVENT_RING] = {nullptr}, ev1[IDIST_EVENT_RING] = {nullptr};
+    uint64_t n_launch = 0;
     // staging for the host-pointer API
     float* d_q = nullptr;
     uint32_t* d_pid = nullptr;
@@ -444,7 +444,8 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const uint32_t grid = std::min(nq, ctx->slots);
     IndexView view = ix->view();
     HIPCHK(hipMemsetAsync(ctx->d_next, 0, 4, stream));
-    HIPCHK(hipEventRecord(ctx->ev0, stream));
+    const uint32_t slot = (uint32_t)(ctx->n_launch % IDIST_EVENT_RING);
+    HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
 #define LAUNCH_SEARCH(NB_, RS_, TAIL_)                      \
     {                                                       \
         auto kS = search_kernel<NB_, RS_, TAIL_>;           \
@@ -453,8 +454,8 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     IDIST_DISPATCH(ix->L, LAUNCH_SEARCH);
 #undef LAUNCH_SEARCH
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev1, stream));
-    ctx->timed = true;
+    HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
+    ctx->n_launch++;
     return IDIST_OK;
 }
 
@@ -681,8 +682,10 @@ idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_
     if ((e = hipMalloc((void**)&c->d_next, 256)) != hipSuccess) return bail(e);
     if ((e = hipMemset(c->d_next, 0, 256)) != hipSuccess) return bail(e);
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail(e);
-    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail(e);
-    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail(e);
+    for (uint32_t i = 0; i < IDIST_EVENT_RING; i++) {
+        if ((e = hipEventCreate(&c->ev0[i])) != hipSuccess) return bail(e);
+        if ((e = hipEventCreate(&c->ev1[i])) != hipSuccess) return bail(e);
+    }
     *out = c;
     return IDIST_OK;
 }
@@ -698,8 +701,10 @@ void idist_search_ctx_free(idist_search_ctx* c) {
     hipFree(c->d_dist);
     hipFree(c->d_cnt);
     hipFree(c->d_ctr);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
+    for (uint32_t i = 0; i < IDIST_EVENT_RING; i++) {
+        if (c->ev0[i]) hipEventDestroy(c->ev0[i]);
+        if (c->ev1[i]) hipEventDestroy(c->ev1[i]);
+    }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -731,9 +736,23 @@ idist_status idist_search_ctx_status(idist_search_ctx* ctx) {
 
 idist_status idist_search_ctx_last_kernel_ms(idist_search_ctx* ctx, float* ms) {
     if (!ctx || !ms) return fail(IDIST_ERR_INVALID_ARG, "null argument");
-    if (!ctx->timed) return fail(IDIST_ERR_INVALID_ARG, "no search kernel has been launched on this ctx");
-    HIPCHK(hipEventSynchronize(ctx->ev1));
-    HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    if (!ctx->n_launch) return fail(IDIST_ERR_INVALID_ARG, "no search kernel has been launched on this ctx");
+    const uint32_t slot = (uint32_t)((ctx->n_launch - 1) % IDIST_EVENT_RING);
+    HIPCHK(hipEventSynchronize(ctx->ev1[slot]));
+    HIPCHK(hipEventElapsedTime(ms, ctx->ev0[slot], ctx->ev1[slot]));
+    return IDIST_OK;
+}
+
+idist_status idist_search_ctx_kernel_times(idist_search_ctx* ctx, float* ms, uint32_t cap, uint32_t* n_out) {
+    if (!ctx || !ms || !n_out) return fail(IDIST_ERR_INVALID_ARG, "null argument");
+    const uint64_t have = std::min<uint64_t>(ctx->n_launch, IDIST_EVENT_RING);
+    const uint32_t take = (uint32_t)std::min<uint64_t>(have, cap);
+    for (uint32_t i = 0; i < take; i++) {
+        const uint32_t slot = (uint32_t)((ctx->n_launch - take + i) % IDIST_EVENT_RING);
+        HIPCHK(hipEventSynchronize(ctx->ev1[slot]));
+        HIPCHK(hipEventElapsedTime(&ms[i], ctx->ev0[slot], ctx->ev1[slot]));
+    }
+    *n_out = take;
     return IDIST_OK;
 }
 
