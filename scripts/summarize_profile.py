@@ -1,67 +1,99 @@
-"""Condense rocprofv3 outputs of scripts/profile_bench.sh into one JSON (for profiles/)."""
-import csv
+"""Condense the rocprofv3 (rocpd SQLite) outputs of scripts/profile_bench.sh into one JSON
++ a markdown summary for profiles/.  Usage: summarize_profile.py gpurun_out/<tag> [profiles/<name>]"""
 import glob
 import json
 import os
+import sqlite3
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+dest = sys.argv[2] if len(sys.argv) > 2 else None
 res = {}
-
-
-def find(sub, pat):
-    return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
+KEYS = ("search_kernel", "build_insert_kernel", "build_update_kernel", "bruteforce_kernel", "distance_batch_kernel",
+        "permute_rows_kernel", "snapshot_kernel", "validate_rows_kernel")
 
 
 def short(name):
-    for k in ("search_kernel", "build_insert_kernel", "build_update_kernel", "bruteforce_kernel", "distance_batch_kernel",
-              "permute_rows_kernel", "snapshot_kernel", "validate_rows_kernel"):
+    for k in KEYS:
         if k in name:
             return k
-    return name[:60]
+    return None
 
 
-# kernel stats
-for f in find("trace", "*kernel_stats.csv"):
-    rows = list(csv.DictReader(open(f)))
-    res["kernel_stats"] = [{k: r[k] for k in r} for r in rows[:12]]
-# per-kernel average from the trace itself
-for f in find("trace", "*kernel_trace.csv"):
-    agg = defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
-        name = short(r.get("Kernel_Name", ""))
-        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-        agg[name][0] += 1
-        agg[name][1] += dur
-    res["kernel_trace_avg_ms"] = {k: {"calls": v[0], "total_ms": round(v[1], 3), "avg_ms": round(v[1] / v[0], 4)} for k, v in agg.items()}
+def dbs(sub):
+    return sorted(glob.glob(os.path.join(out, sub, "**", "*_results.db"), recursive=True))
+
+
+for f in dbs("trace"):
+    cur = sqlite3.connect(f).cursor()
+    rows = cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
+    res["kernel_stats"] = [{"kernel": r[0][:90], "calls": r[1], "total_us": round(r[2], 1), "avg_us": round(r[3], 1),
+                            "pct": round(r[4], 3)} for r in rows[:8]]
+    rows = cur.execute("select name, vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x from kernels "
+                       "group by name").fetchall()
+    res["kernel_resources"] = {short(r[0]): {"vgpr": r[1], "sgpr": r[2], "lds_bytes": r[3], "scratch": r[4],
+                                              "workgroup": r[5], "grid_threads_example": r[6]} for r in rows if short(r[0])}
 
 
 def pmc(sub, counter):
     agg = defaultdict(list)
-    for f in find(sub, "*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == counter:
-                agg[short(r.get("Kernel_Name", ""))].append(float(r["Counter_Value"]))
-    return {k: {"dispatches": len(v), "mean": sum(v) / len(v), "last": v[-1], "max": max(v)} for k, v in agg.items()}
+    for f in dbs(sub):
+        cur = sqlite3.connect(f).cursor()
+        for k, c, v, d in cur.execute("select kernel_name, counter_name, value, duration from counters_collection"):
+            if c == counter and short(k):
+                agg[short(k)].append((v, d))
+    return {k: {"dispatches": len(v), "mean_KB": round(sum(x[0] for x in v) / len(v), 1), "last_KB": round(v[-1][0], 1),
+                "sum_KB": round(sum(x[0] for x in v), 1), "mean_ms": round(sum(x[1] for x in v) / len(v) / 1e6, 3)} for k, v in agg.items()}
 
 
-res["pmc_FETCH_SIZE_KB"] = pmc("pmc_fetch", "FETCH_SIZE")
-res["pmc_WRITE_SIZE_KB"] = pmc("pmc_write", "WRITE_SIZE")
-res["calib_FETCH_SIZE_KB"] = pmc("calib_fetch", "FETCH_SIZE")
+res["pmc_FETCH_SIZE"] = pmc("pmc_fetch", "FETCH_SIZE")
+res["pmc_WRITE_SIZE"] = pmc("pmc_write", "WRITE_SIZE")
+res["calib_FETCH_SIZE"] = pmc("calib_fetch", "FETCH_SIZE")
+factor = None
 try:
     known = None
     for line in open(os.path.join(out, "calib_fetch.log")):
         if line.startswith("known_read_bytes_per_launch"):
             known = int(line.split()[1])
-    c = res["calib_FETCH_SIZE_KB"].get("distance_batch_kernel")
+    c = res["calib_FETCH_SIZE"].get("distance_batch_kernel")
     if known and c:
-        res["calibration"] = {"known_read_bytes": known, "reported_bytes": c["last"] * 1024,
-                              "correction_factor": known / (c["last"] * 1024)}
+        factor = known / (c["last_KB"] * 1024)
+        res["calibration"] = {"kernel": "distance_batch_kernel over a random permutation of all 1M rows (8 lanes x float4 per row)",
+                              "known_read_bytes": known, "reported_bytes": c["last_KB"] * 1024,
+                              "correction_factor": round(factor, 4),
+                              "note": "gfx950 FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md §HBM)"}
 except Exception as e:  # noqa: BLE001
     res["calibration_error"] = str(e)
 try:
     res["bench"] = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
 except Exception as e:  # noqa: BLE001
     res["bench_error"] = str(e)
+sf, sw = res["pmc_FETCH_SIZE"].get("search_kernel"), res["pmc_WRITE_SIZE"].get("search_kernel")
+if sf and sw and factor:
+    fetch = sf["last_KB"] * 1024 * factor
+    write = sw["last_KB"] * 1024
+    res["traffic"] = {"search_kernel_fetch_bytes_raw": sf["last_KB"] * 1024, "search_kernel_fetch_bytes_corrected": round(fetch),
+                      "search_kernel_write_bytes": round(write), "search_kernel_hbm_bytes_per_launch": round(fetch + write)}
+    if "bench" in res:
+        alg = res["bench"]["roofline"]["alg_bytes_per_launch"]
+        res["traffic"]["alg_bytes_per_launch"] = alg
+        res["traffic"]["traffic_over_algorithmic"] = round((fetch + write) / alg, 3)
 print(json.dumps(res, indent=1))
+if dest:
+    json.dump(res, open(dest + ".json", "w"), indent=1)
+    if "traffic" in res:
+        json.dump(res["traffic"], open(os.path.join(os.path.dirname(dest), "traffic_" + os.path.basename(dest).split("_")[-1] + ".json"), "w"), indent=1)
+    with open(dest + ".md", "w") as f:
+        f.write(f"# rocprofv3 summary ({os.path.basename(dest)})\n\nCommand: `python bench.py` (C3: 1M x 300-d, 10k queries, ef_search=100) under "
+                "`rocprofv3 --kernel-trace --stats`, then separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes.\n\n")
+        f.write("## kernel-trace --stats (top kernels)\n\n| kernel | calls | total µs | avg µs | % |\n|---|---|---|---|---|\n")
+        for r in res.get("kernel_stats", []):
+            f.write(f"| `{r['kernel'][:70]}` | {r['calls']} | {r['total_us']} | {r['avg_us']} | {r['pct']} |\n")
+        f.write("\n## resources\n\n```\n" + json.dumps(res.get("kernel_resources", {}), indent=1) + "\n```\n")
+        f.write("\n## PMC (per dispatch, KB as reported)\n\n```\nFETCH_SIZE " + json.dumps(res["pmc_FETCH_SIZE"], indent=1) +
+                "\nWRITE_SIZE " + json.dumps(res["pmc_WRITE_SIZE"], indent=1) + "\n```\n")
+        f.write("\n## FETCH_SIZE calibration on the gather pattern\n\n```\n" + json.dumps(res.get("calibration", {}), indent=1) + "\n```\n")
+        f.write("\n## search_kernel HBM traffic per launch\n\n```\n" + json.dumps(res.get("traffic", {}), indent=1) + "\n```\n")
+        if "bench" in res:
+            f.write("\n## bench line of the same session\n\n```json\n" + json.dumps(res["bench"]) + "\n```\n")

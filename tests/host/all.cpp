@@ -1,0 +1,95 @@
+// Replays the reference's integration tests (instant-distance/tests/all.rs) and its
+// example (examples/colors.rs) through the C++ host mirror of the Rust API.
+// Exit code 0 = all assertions hold.  Built by tests/test_host_cpp.py against either
+// libidist.so (GPU) or the emulated library (CPU).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <set>
+#include <string>
+
+#include "../../instant-distance_amd/host/instant_distance.hpp"
+
+using namespace instant_distance;
+
+#define REQUIRE(c)                                                        \
+    do {                                                                  \
+        if (!(c)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); exit(1); } \
+    } while (0)
+
+// tests/all.rs:90-98
+struct Point {
+    float x, y;
+    static constexpr int METRIC = IDIST_METRIC_L2;
+    size_t dim() const { return 2; }
+    void write_f32(float* o) const { o[0] = x; o[1] = y; }
+    float distance(const Point& o) const { return std::sqrt((x - o.x) * (x - o.x) + (y - o.y) * (y - o.y)); }
+};
+// examples/colors.rs:17-26 (isize coordinates <= 255 are exact in f32)
+struct Color {
+    long r, g, b;
+    static constexpr int METRIC = IDIST_METRIC_L2;
+    size_t dim() const { return 3; }
+    void write_f32(float* o) const { o[0] = (float)r; o[1] = (float)g; o[2] = (float)b; }
+};
+
+static void map(uint64_t seed) {  // tests/all.rs:11-39
+    std::vector<Point> points;
+    for (int i = 0; i < 5; i++) points.push_back(Point{(float)i, (float)i});
+    std::vector<std::string> values = {"zero", "one", "two", "three", "four"};
+    auto m = Builder::default_().seed(seed).build(points, values);
+    Search search;
+    int i = 0;
+    for (auto& item : m.search(Point{2.0f, 2.0f}, search)) {
+        if (i == 0) { REQUIRE(item.distance == 0.0f); REQUIRE(*item.value == "two"); }
+        else if (i <= 2) { REQUIRE(item.distance == 1.4142135f); REQUIRE(*item.value == "one" || *item.value == "three"); }
+        else if (i <= 4) { REQUIRE(item.distance == 2.828427f); REQUIRE(*item.value == "zero" || *item.value == "four"); }
+        else REQUIRE(false);
+        i++;
+    }
+    REQUIRE(i == 5);
+}
+
+static size_t randomized(Builder builder, uint64_t seed, int n) {  // tests/all.rs:55-88
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<float> u(0.0f, 1.0f);
+    std::vector<Point> points;
+    for (int i = 0; i < n; i++) points.push_back(Point{u(rng), u(rng)});
+    Point query{u(rng), u(rng)};
+    std::vector<std::pair<float, int>> nearest;
+    for (int i = 0; i < n; i++) nearest.push_back({query.distance(points[i]), i});
+    std::sort(nearest.begin(), nearest.end());
+    auto [hnsw, pids] = std::move(builder).seed(seed).build_hnsw(points);
+    Search search;
+    auto results = hnsw.search(query, search);
+    REQUIRE((int)results.size() >= std::min(n, 100));
+    std::set<uint32_t> forced, found;
+    for (int i = 0; i < 100 && i < n; i++) forced.insert(pids[nearest[i].second].v);
+    for (int i = 0; i < 100 && i < (int)results.size(); i++) found.insert(results[i].pid.v);
+    size_t both = 0;
+    for (auto p : forced) both += found.count(p);
+    return both;
+}
+
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 1024;
+    for (uint64_t seed = 0; seed < 4; seed++) map(seed);
+    size_t recall = randomized(Builder::default_(), 123456789ull, n);
+    printf("heuristic recall = %zu\n", recall);
+    REQUIRE(recall > 97);                          // tests/all.rs:45
+    // select_heuristic(None) is reported, not silently mis-built (tests/all.rs:48-53)
+    try {
+        randomized(Builder::default_().select_heuristic(nullptr), 1, 64);
+        REQUIRE(false);
+    } catch (const Error& e) { REQUIRE(e.status == IDIST_ERR_UNSUPPORTED); }
+    // examples/colors.rs
+    std::vector<Color> colors = {{255, 0, 0}, {0, 255, 0}, {0, 0, 255}};
+    std::vector<std::string> names = {"red", "green", "blue"};
+    auto cm = Builder::default_().seed(3).build(colors, names);
+    Search s;
+    REQUIRE(*cm.search(Color{204, 85, 0}, s).front().value == "red");
+    REQUIRE(*cm.search(Color{163, 193, 173}, s).front().value == "green");
+    printf("host api ok\n");
+    return 0;
+}
