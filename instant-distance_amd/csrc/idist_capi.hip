@@ -282,7 +282,15 @@ idist_status run_build(idist_index* ix) {
     const size_t smem = smem_bytes(ix->L.stride, wcap, true);
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave (> 64 KiB)", smem);
 
+    // step B tile: as many selected rows on chip as fit 64 KiB of LDS next to 8 staging slots
+    uint32_t rt = 16;
+    if (const char* e = getenv("IDIST_BUILD_RT")) rt = (uint32_t)atoi(e);
+    while (rt > 0 && smem_bytes_update(ix->L.nb, rt) > 64 * 1024) rt--;
+    const size_t smemB = smem_bytes_update(ix->L.nb, rt);
+    if (smemB > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim %u needs %zu B of LDS per wave in the build (> 64 KiB)", ix->dim, smemB);
+
     uint8_t *d_vis = nullptr, *d_gen = nullptr;
+    uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
     uint32_t* d_small = nullptr;           // [0] n_touched, [1..2] queue, [3] status
     unsigned long long* d_stats = nullptr; // [8]
@@ -290,6 +298,7 @@ idist_status run_build(idist_index* ix) {
     const size_t n_touch = std::min<size_t>(n_edges, n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto release = [&]() {
+        hipFree(d_nbr_dist);
         hipFree(d_vis); hipFree(d_gen); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
         if (e0) hipEventDestroy(e0);
@@ -307,6 +316,8 @@ idist_status run_build(idist_index* ix) {
     BCHK(hipMemset(d_vis, 0, (size_t)slots * vis_stride));
     BCHK(hipMalloc((void**)&d_gen, std::max<size_t>(slots, 256)));
     BCHK(hipMemset(d_gen, 0, std::max<size_t>(slots, 256)));
+    BCHK(hipMalloc((void**)&d_nbr_dist, (size_t)n * IDIST_M2 * 4));
+    BCHK(hipMemset(d_nbr_dist, 0, (size_t)n * IDIST_M2 * 4));
     BCHK(hipMalloc((void**)&d_edge_pid, n_edges * 4));
     BCHK(hipMalloc((void**)&d_edge_dist, n_edges * 4));
     BCHK(hipMalloc((void**)&d_next, n_edges * 4));
@@ -334,6 +345,8 @@ idist_status run_build(idist_index* ix) {
     a.head = d_head;
     a.next = d_next;
     a.touched = d_touched;
+    a.nbr_dist = d_nbr_dist;
+    a.rt = rt;
     a.n_touched = d_small;
     a.queue = d_small + 1;
     a.status = d_small + 3;
@@ -366,7 +379,7 @@ idist_status run_build(idist_index* ix) {
         auto kA = build_insert_kernel<NB_, RS_, TAIL_>;                                            \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         IDIST_LAUNCH(kA, gridA, 64, smem, stream, view, a);                                        \
-        IDIST_LAUNCH(kB, gridB, 64, smem, stream, view, a);                                        \
+        IDIST_LAUNCH(kB, gridB, 64, smemB, stream, view, a);                                       \
     }
             IDIST_DISPATCH(ix->L, LAUNCH_BUILD);
 #undef LAUNCH_BUILD

@@ -82,6 +82,15 @@ __device__ __forceinline__ uint32_t canon_bits(float r, uint32_t metric) {
     return b;
 }
 
+// An LDS-resident blocked vector: block t (32 floats) at blk + t*bstride, the
+// natural-order remainder (rem steps + tail) at rem.
+struct VecView {
+    const float* blk;
+    int bstride;
+    const float* rem;
+};
+__device__ __forceinline__ VecView natural_view(const float* q, int nb) { return VecView{q, 32, q + nb * 32}; }
+
 // ---------------------------------------------------------------------------
 // Canonical distances of `na` rows (pids in act_pid[0..na)) to the LDS-resident
 // blocked vector q.  Result bits -> act_dist[0..na).  Group g = lane>>3 takes
@@ -89,6 +98,9 @@ __device__ __forceinline__ uint32_t canon_bits(float r, uint32_t metric) {
 // ---------------------------------------------------------------------------
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q, const uint32_t* act_pid,
+                                            uint32_t* act_dist, int na);
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ void dist_rounds(const IndexView& ix, const VecView qv, const uint32_t* act_pid,
                                             uint32_t* act_dist, int na) {
     const int lane = lane_id();
     const int g = lane >> 3, j = lane & 7;
@@ -113,7 +125,7 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q,
 #pragma unroll
                     for (int u = 0; u < CH; u++) {
                         if (t0 + u < NB) {
-                            const float4 w = *reinterpret_cast<const float4*>(q + (t0 + u) * 32 + j * 4);
+                            const float4 w = *reinterpret_cast<const float4*>(qv.blk + (t0 + u) * qv.bstride + j * 4);
                             float d;
                             d = w.x - p[u].x; acc = __builtin_fmaf(d, d, acc);
                             d = w.y - p[u].y; acc = __builtin_fmaf(d, d, acc);
@@ -125,7 +137,7 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q,
             } else {
                 for (int t = 0; t < nb; t++) {
                     const float4 p = *reinterpret_cast<const float4*>(row + t * 32 + j * 4);
-                    const float4 w = *reinterpret_cast<const float4*>(q + t * 32 + j * 4);
+                    const float4 w = *reinterpret_cast<const float4*>(qv.blk + t * qv.bstride + j * 4);
                     float d;
                     d = w.x - p.x; acc = __builtin_fmaf(d, d, acc);
                     d = w.y - p.y; acc = __builtin_fmaf(d, d, acc);
@@ -134,22 +146,25 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q,
                 }
             }
             for (int c = 0; c < rs; c++) {   // py/lib.rs:391-396, steps not filling a block
-                const int o = nb * 32 + c * 8 + j;
-                const float d = q[o] - row[o];
+                const float d = qv.rem[c * 8 + j] - row[nb * 32 + c * 8 + j];
                 acc = __builtin_fmaf(d, d, acc);
             }
         }
         // acc_4x = hi128 + lo128, py/lib.rs:398-400 (lanes j and j^4 hold the same sum)
         float a4 = acc + __shfl_xor(acc, 4, 64);
         if (tail && on) {                    // 4-wide tail, py/lib.rs:402-405
-            const int o = nb * 32 + rs * 8 + (j & 3);
-            const float d = q[o] - row[o];
+            const float d = qv.rem[rs * 8 + (j & 3)] - row[nb * 32 + rs * 8 + (j & 3)];
             a4 = __builtin_fmaf(d, d, a4);
         }
         const float s = a4 + __shfl_xor(a4, 2, 64);   // (s0+s2),(s1+s3): movehl+add, :407-408
         const float r = s + __shfl_xor(s, 1, 64);     // add_ss, :409-411
         if (on && j == 0) act_dist[k] = canon_bits(r, ix.metric);
     }
+}
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q, const uint32_t* act_pid,
+                                            uint32_t* act_dist, int na) {
+    dist_rounds<NB, RS, TAIL>(ix, natural_view(q, NB >= 0 ? NB : (int)ix.nb), act_pid, act_dist, na);
 }
 
 // ---------------------------------------------------------------------------
@@ -405,6 +420,200 @@ __device__ __forceinline__ int select_heuristic(const IndexView& ix, const uint6
         wave_sync();
     }
     if (keep_pruned) {                                     // :687-695
+        int take = kM2 - nsel;
+        if (take > ndis) take = ndis;
+        if (lane < take) sel[nsel + lane] = disc[lane];
+        if (take > 0) nsel += take;
+        wave_sync();
+    }
+    return nsel;
+}
+
+
+// ---------------------------------------------------------------------------
+// select_heuristic with the selected rows kept on chip (build step B).
+// Tile layout (LDS): blk[t][slot][32] for the full 128-B blocks, rem[slot][32]
+// for the natural-order remainder.  Slots [0, rt) hold R (the selected set, in
+// selection order), slots [rt, rt+fc) stage the next fc candidates, fetched
+// together so their HBM latencies overlap.  Consecutive slots are 32 dwords
+// apart => the 8 row-groups of a ds_read_b128 round hit disjoint banks.
+// Selected rows beyond rt are compared through the global gather path.
+// ---------------------------------------------------------------------------
+struct Tile {
+    float* blk;
+    float* rem;
+    int slots;   // rt + fc
+    int rt, fc;
+};
+__device__ __forceinline__ VecView tile_view(const Tile& t, int slot) {
+    return VecView{t.blk + slot * 32, t.slots * 32, t.rem + slot * 32};
+}
+__host__ __device__ inline size_t tile_floats(uint32_t nb, uint32_t slots) { return (size_t)(nb + 1) * slots * 32; }
+
+// float4 #f of a stored row -> its place in slot `slot` (branch-free: rem == blk + nb*slots*32)
+__device__ __forceinline__ float* tile_addr(const Tile& t, int nb, int slot, int f) {
+    const int off_blk = (((f >> 3) * t.slots + slot) << 5) + ((f & 7) << 2);
+    const int off_rem = ((nb * t.slots + slot) << 5) + ((f - 8 * nb) << 2);
+    return t.blk + (f < 8 * nb ? off_blk : off_rem);
+}
+
+// (kept out of line: inlined into the selection loop hipcc demotes the staging registers to scratch)
+template <int NB, int RS, int TAIL>
+__device__ __attribute__((noinline)) void tile_stage(const float* __restrict__ points, uint32_t stride, uint32_t nb_rt,
+                                                     float* tblk, int tslots, int first_slot, const uint32_t* pids, int cnt) {
+    const int lane = lane_id();
+    const int nb = NB >= 0 ? NB : (int)nb_rt;
+    const int nf4 = (int)stride >> 2;
+    Tile t;
+    t.blk = tblk;
+    t.rem = tblk + (size_t)nb * tslots * 32;
+    t.slots = tslots;
+    t.rt = first_slot;
+    t.fc = 8;
+    struct { const float* points; uint32_t stride; } ix{points, stride};
+    if constexpr (NB >= 0) {
+        constexpr int USED = 32 * NB + 8 * RS + 4 * TAIL;
+        constexpr int STRIDE = USED <= 16 ? 16 : ((USED + 15) & ~15);
+        constexpr int NF = (STRIDE / 4 + 63) / 64;
+        constexpr int FC = 8;
+        float4 v[FC][NF];
+        // branch-free: slots past cnt re-fetch the last candidate (never read), so every load of the
+        // chunk is in flight before the first LDS store
+#pragma unroll
+        for (int u = 0; u < FC; u++) {
+            const int uu = u < cnt ? u : cnt - 1;
+            const float* row = ix.points + (size_t)pids[uu] * ix.stride;
+#pragma unroll
+            for (int k = 0; k < NF; k++) {
+                const int f = lane + 64 * k;
+                v[u][k] = *reinterpret_cast<const float4*>(row + 4 * (f < STRIDE / 4 ? f : 0));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FC; u++) {
+#pragma unroll
+            for (int k = 0; k < NF; k++) {
+                const int f = lane + 64 * k;
+                if (f < STRIDE / 4) *reinterpret_cast<float4*>(tile_addr(t, NB, first_slot + u, f)) = v[u][k];
+            }
+        }
+    } else {
+        for (int u = 0; u < cnt; u++) {
+            const float* row = ix.points + (size_t)pids[u] * ix.stride;
+            for (int f = lane; f < nf4; f += 64)
+                *reinterpret_cast<float4*>(tile_addr(t, nb, first_slot + u, f)) = *reinterpret_cast<const float4*>(row + 4 * f);
+        }
+    }
+}
+
+__device__ __forceinline__ void tile_copy(const IndexView& ix, const Tile& t, int nb, int dst, int src) {
+    const int lane = lane_id();
+    const int nf4 = (int)ix.stride >> 2;
+    for (int f = lane; f < nf4; f += 64)
+        *reinterpret_cast<float4*>(tile_addr(t, nb, dst, f)) = *reinterpret_cast<const float4*>(tile_addr(t, nb, src, f));
+}
+
+// any R[b..b+cnt) (slots b..) closer to the candidate in slot `cslot` than cd?  (core/lib.rs:676-679)
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ bool tile_any_closer(const IndexView& ix, const Tile& t, int cslot, int b, int cnt, uint32_t cd) {
+    const int lane = lane_id();
+    const int g = lane >> 3, j = lane & 7;
+    const int nb = NB >= 0 ? NB : (int)ix.nb;
+    const int rs = RS >= 0 ? RS : (int)ix.rs;
+    const int tail = TAIL >= 0 ? TAIL : (int)ix.tail;
+    const bool on = g < cnt;
+    const int rslot = on ? b + g : cslot;
+    const float* cb = t.blk + (cslot << 5) + (j << 2);
+    const float* rb = t.blk + (rslot << 5) + (j << 2);
+    const int bs = t.slots << 5;
+    float acc = 0.0f;
+    if constexpr (NB >= 0) {
+#pragma unroll
+        for (int tt = 0; tt < NB; tt++) {
+            const float4 w = *reinterpret_cast<const float4*>(cb + tt * bs);
+            const float4 p = *reinterpret_cast<const float4*>(rb + tt * bs);
+            float d;
+            d = w.x - p.x; acc = __builtin_fmaf(d, d, acc);
+            d = w.y - p.y; acc = __builtin_fmaf(d, d, acc);
+            d = w.z - p.z; acc = __builtin_fmaf(d, d, acc);
+            d = w.w - p.w; acc = __builtin_fmaf(d, d, acc);
+        }
+    } else {
+        for (int tt = 0; tt < nb; tt++) {
+            const float4 w = *reinterpret_cast<const float4*>(cb + tt * bs);
+            const float4 p = *reinterpret_cast<const float4*>(rb + tt * bs);
+            float d;
+            d = w.x - p.x; acc = __builtin_fmaf(d, d, acc);
+            d = w.y - p.y; acc = __builtin_fmaf(d, d, acc);
+            d = w.z - p.z; acc = __builtin_fmaf(d, d, acc);
+            d = w.w - p.w; acc = __builtin_fmaf(d, d, acc);
+        }
+    }
+    const float* cr = t.rem + (cslot << 5);
+    const float* rr = t.rem + (rslot << 5);
+    for (int c = 0; c < rs; c++) {
+        const float d = cr[c * 8 + j] - rr[c * 8 + j];
+        acc = __builtin_fmaf(d, d, acc);
+    }
+    float a4 = acc + __shfl_xor(acc, 4, 64);
+    if (tail) {
+        const float d = cr[rs * 8 + (j & 3)] - rr[rs * 8 + (j & 3)];
+        a4 = __builtin_fmaf(d, d, a4);
+    }
+    const float s = a4 + __shfl_xor(a4, 2, 64);
+    const float r = s + __shfl_xor(s, 1, 64);
+    const bool closer = on && j == 0 && canon_bits(r, ix.metric) < cd;   // strict <, core/lib.rs:678
+    return __ballot(closer) != 0ull;
+}
+
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ int select_heuristic_tiled(const IndexView& ix, const uint64_t* Wsrc, int nw, bool keep_pruned,
+                                                      const Tile& t, uint64_t* sel, uint64_t* disc, uint32_t* act_pid,
+                                                      uint32_t* act_dist, HeurCounters& hc) {
+    const int lane = lane_id();
+    const int nb = NB >= 0 ? NB : (int)ix.nb;
+    int nsel = 0, ndis = 0;
+    for (int w0 = 0; w0 < nw && nsel < kM2; w0 += t.fc) {           // core/lib.rs:668-671
+        const int cnt = nw - w0 < t.fc ? nw - w0 : t.fc;
+        if (lane < cnt) act_pid[lane] = (uint32_t)Wsrc[w0 + lane];
+        wave_sync();
+        tile_stage<NB, RS, TAIL>(ix.points, ix.stride, ix.nb, t.blk, t.slots, t.rt, act_pid, cnt);   // points[candidate.pid], :675
+        hc.n_rows += (uint32_t)cnt;
+        wave_sync();
+        for (int u = 0; u < cnt && nsel < kM2; u++) {
+            const uint64_t c = Wsrc[w0 + u] & kKeyMask;
+            const uint32_t cd = (uint32_t)(c >> 32);
+            const int cslot = t.rt + u;
+            bool pruned = false;
+            const int nl = nsel < t.rt ? nsel : t.rt;                // `any`, :676-679, early exit per 8
+            for (int b = 0; b < nl && !pruned; b += 8) {
+                const int c8 = nl - b < 8 ? nl - b : 8;
+                pruned = tile_any_closer<NB, RS, TAIL>(ix, t, cslot, b, c8, cd);
+                hc.n_dist += (uint32_t)c8;
+            }
+            for (int b = t.rt; b < nsel && !pruned; b += 8) {        // selected rows that did not fit on chip
+                const int c8 = nsel - b < 8 ? nsel - b : 8;
+                wave_sync();
+                if (lane < c8) act_pid[8 + lane] = (uint32_t)sel[b + lane];
+                wave_sync();
+                dist_rounds<NB, RS, TAIL>(ix, tile_view(t, cslot), act_pid + 8, act_dist, c8);
+                wave_sync();
+                hc.n_dist += (uint32_t)c8;
+                pruned = __ballot(lane < c8 && act_dist[lane] < cd) != 0ull;
+            }
+            if (!pruned) {                                           // :681-684
+                if (lane == 0) sel[nsel] = c;
+                if (nsel < t.rt) tile_copy(ix, t, nb, nsel, cslot);
+                nsel++;
+            } else {
+                if (lane == 0 && ndis < kM2) disc[ndis] = c;
+                ndis++;
+            }
+            wave_sync();
+        }
+    }
+    if (keep_pruned) {                                               // :687-695
+        if (ndis > kM2) ndis = kM2;
         int take = kM2 - nsel;
         if (take > ndis) take = ndis;
         if (lane < take) sel[nsel + lane] = disc[lane];

@@ -284,6 +284,8 @@ struct BuildArgs {
     uint32_t* next;             // [max_batch*64] inbox links
     uint32_t* touched;          // distinct nodes with a non-empty inbox
     uint32_t* n_touched;
+    uint32_t* nbr_dist;         // [n][64] distance bits of every zero-row entry to its owner (build scratch)
+    uint32_t rt;                // step B: selected rows kept in the LDS tile
     uint32_t* queue;            // work queue heads: [0] step A, [1] step B
     unsigned long long* stats;  // [8] n_dist n_exp0 n_expU n_heur_dist n_heur_rows n_updates
     uint32_t* status;
@@ -337,6 +339,7 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
                                                         sm.act_pid, sm.act_dist, hc);  // :470-472
         // node.set(i, pid) for every found neighbour (:516); the row was all-INVALID
         ix.zero[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
+        a.nbr_dist[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)(sel[lane] >> 32) : 0u;
         if (lane < nsel) {
             const uint64_t k = sel[lane];
             const uint32_t e = item * kM2 + (uint32_t)lane;
@@ -369,14 +372,34 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
 // :616-631; core/types.rs:88-98).  With one new point per step this is the
 // reference's loop body verbatim; with several, all new points that chose the
 // node are pushed (nearest first) before its single re-selection.
+//
+// On-chip working set: the distances of the current neighbours are kept next to
+// the ids (nbr_dist, bit-identical to recomputing them: the canonical distance
+// is symmetric), candidate rows are fetched 8 at a time into an LDS tile, and
+// the selected set stays in that tile, so every row crosses HBM once per update.
 // ---------------------------------------------------------------------------
+constexpr int kUpdW = 136;   // <= 64 current + 64 new + slack
+__host__ __device__ inline size_t smem_bytes_update(uint32_t nb, uint32_t rt) {
+    return tile_floats(nb, rt + 8) * 4 + (size_t)(kUpdW + 72 + 64 + 64 + 64) * 8 + 2 * 64 * 4;
+}
+
 template <int NB, int RS, int TAIL>
 __global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArgs a) {
     IDIST_DYN_SMEM(smem_raw);
-    const Smem sm = carve(smem_raw, ix.stride, a.wcap, true);
-    uint64_t* news = sm.aux;            // 64 + 8 (sorted, nearest first)
-    uint64_t* sel = sm.aux + 64 + 8;
+    const int nb = NB >= 0 ? NB : (int)ix.nb;
+    Tile tile;
+    tile.rt = (int)a.rt;
+    tile.fc = 8;
+    tile.slots = tile.rt + tile.fc;
+    tile.blk = reinterpret_cast<float*>(smem_raw);
+    tile.rem = tile.blk + (size_t)nb * tile.slots * 32;
+    uint64_t* W = reinterpret_cast<uint64_t*>(tile.blk + tile_floats((uint32_t)nb, (uint32_t)tile.slots));
+    uint64_t* news = W + kUpdW;          // 64 + 8, sorted nearest first
+    uint64_t* sel = news + 72;
     uint64_t* disc = sel + 64;
+    uint64_t* curk = disc + 64;
+    uint32_t* act_pid = reinterpret_cast<uint32_t*>(curk + 64);
+    uint32_t* act_dist = act_pid + 64;
     const int lane = lane_id();
     const uint32_t ntouched = *a.n_touched;
     HeurCounters hc{0, 0};
@@ -401,40 +424,51 @@ __global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArg
             if (++guard > a.count) { status |= kStGuard; break; }
         }
         if (lane == 0) a.head[pid] = kInvalid;
+        const int k_new = ns.plen;
 
-        // point = &points[pid] (:489)
-        const float* prow = ix.points + (size_t)pid * ix.stride;
-        for (uint32_t o = lane * 4; o < ix.stride; o += 256)
-            *reinterpret_cast<float4*>(sm.q + o) = *reinterpret_cast<const float4*>(prow + o);
-        // current = zero.nearest_iter(pid) (:487): all valid slots of the 64
+        // current = zero.nearest_iter(pid) (:487) with the stored distances to points[pid] (:489)
         const uint32_t cur = ix.zero[(size_t)pid * kM2 + lane];
+        const uint32_t curd = a.nbr_dist[(size_t)pid * kM2 + lane];
         const uint64_t inval = __ballot(cur == kInvalid);
         const int ncur = inval ? __builtin_ctzll(inval) : 64;
-        if (lane < ncur) sm.act_pid[lane] = cur;
-        wave_sync();
-        dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, ncur);
-        wave_sync();
-        hc.n_dist += (uint32_t)ncur;
-        uint64_t key = kMaxKey;
-        if (lane < ncur) key = ((uint64_t)sm.act_dist[lane] << 32) | cur;
+        const uint64_t key = lane < ncur ? (((uint64_t)curd << 32) | cur) : kMaxKey;
 
         // insertion.reset(); push(new); push(current...) with ef = ef_construction (:440, :625-629)
-        WState st{sm.W, 0, (int)a.efc, 0, 0u};
-        for (int i = 0; i < ns.plen; i++) {
-            const uint64_t k = news[i] & kKeyMask;
-            const int idx = w_rank(st, k);
-            if (idx < st.ef) w_insert(st, idx, k);
-        }
-        for (int i = 0; i < ncur; i++) {
-            const uint64_t k = bcast_u64(key, i);
-            const int idx = w_rank(st, k);
-            if (idx < st.ef) w_insert(st, idx, k);
+        WState st{W, 0, (int)a.efc, 0, 0u};
+        if (ncur + k_new <= (int)a.efc) {
+            // nothing can be dropped by `idx < ef` => W is simply all keys sorted: parallel rank sort
+            if (lane < ncur) curk[lane] = key;
+            wave_sync();
+            const uint64_t keyb = lane < k_new ? (news[lane] & kKeyMask) : kMaxKey;
+            int ra = 0, rb = lane;
+            for (int i = 0; i < ncur; i++) {
+                const uint64_t o = curk[i];
+                ra += o < key ? 1 : 0;
+                rb += o < keyb ? 1 : 0;
+            }
+            for (int i = 0; i < k_new; i++) ra += (news[i] & kKeyMask) < key ? 1 : 0;
+            if (lane < ncur) W[ra] = key;
+            if (lane < k_new) W[rb] = keyb;
+            st.plen = ncur + k_new;
+            wave_sync();
+        } else {
+            for (int i = 0; i < k_new; i++) {
+                const uint64_t k = news[i] & kKeyMask;
+                const int idx = w_rank(st, k);
+                if (idx < st.ef) w_insert(st, idx, k);
+            }
+            for (int i = 0; i < ncur; i++) {
+                const uint64_t k = bcast_u64(key, i);
+                const int idx = w_rank(st, k);
+                if (idx < st.ef) w_insert(st, idx, k);
+            }
         }
         // select_heuristic over ALL of `nearest` (no truncate in add_neighbor_heuristic, :630)
-        const int nsel = select_heuristic<NB, RS, TAIL>(ix, st.W, st.plen, a.keep_pruned != 0, sm.cq, sel, disc,
-                                                        sm.act_pid, sm.act_dist, hc);
+        const int nsel = select_heuristic_tiled<NB, RS, TAIL>(ix, st.W, st.plen, a.keep_pruned != 0, tile, sel, disc,
+                                                              act_pid, act_dist, hc);
         // ZeroNode::rewrite (core/types.rs:88-98): rows are prefix-valid, so clearing to the end is identical
         ix.zero[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
+        a.nbr_dist[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)(sel[lane] >> 32) : 0u;
         updates++;
         wave_sync();
     }
