@@ -45,6 +45,26 @@ def synth(torch, n, dim, seed, device, latent=32):
     return out
 
 
+def effective_cores():
+    """Host cores this process may actually use: min(affinity, cgroup CPU quota)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    cores = min(cores, max(1, quota // period))
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    return cores
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,7 +218,7 @@ def main():
             zero, layers = hnsw.into_parts()
             pts_h = d_pts.cpu().numpy()
             oix = po.Index.from_arrays(pts_h, zero, layers, po.default_config(ef_search=chosen))
-            cores = os.cpu_count() or 1
+            cores = effective_cores()
             q_h = d_q.cpu().numpy()
             # bounded sample: ~10-30 core-seconds of CPU work; best of 3 passes (thread start-up noise)
             probe = min(nq, 8 * cores)
@@ -210,7 +230,8 @@ def main():
                 t0 = time.perf_counter(); ores = oix.search(q_h[:sample], threads=cores); tc = min(tc, time.perf_counter() - t0)
             same = bool(np.array_equal(ores.pid, outs[0][:sample].cpu().numpy().astype(np.uint32)))
             cpu = {"value": round(sample / tc, 1), "unit": "queries/s", "cores": cores, "kind": "port",
-                   "sample": f"first {sample} of the {nq} queries, same graph, ef_search={chosen}, {cores} threads "
+                   "sample": f"first {sample} of the {nq} queries, same graph, ef_search={chosen}, {cores} threads = the "
+                             f"container's CPU quota ({os.cpu_count()} logical CPUs visible) "
                              "(C oracle = restated reference, not the Rust crate)",
                    "seconds": round(tc, 2), "ids_identical_to_gpu": same}
 

@@ -99,6 +99,8 @@ typedef struct idist_build_stats {
     uint64_t n_heur_dist;   /* pairwise distances inside select_heuristic + neighbour re-selection */
     uint64_t n_heur_rows;   /* candidate rows staged for select_heuristic */
     uint64_t n_updates;     /* neighbour rows rewritten (ZeroNode::rewrite) */
+    uint64_t n_updates_fast; /* ... of which through the memoised re-selection */
+    uint64_t n_updates_full; /* ... of which through the full re-selection */
     uint64_t n_batches;
     double seconds;         /* device time of the whole build (HIP events) */
 } idist_build_stats;

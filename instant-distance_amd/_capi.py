@@ -65,6 +65,7 @@ class BuildStats(C.Structure):
     _fields_ = [
         ("n_dist", C.c_uint64), ("n_exp0", C.c_uint64), ("n_expU", C.c_uint64),
         ("n_heur_dist", C.c_uint64), ("n_heur_rows", C.c_uint64), ("n_updates", C.c_uint64),
+        ("n_updates_fast", C.c_uint64), ("n_updates_full", C.c_uint64),
         ("n_batches", C.c_uint64), ("seconds", C.c_double),
     ]
 

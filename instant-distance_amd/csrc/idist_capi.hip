@@ -62,6 +62,10 @@ Layout make_layout(uint32_t dim) {
     L.rs = steps % 4u;
     const uint32_t used = 32u * L.nb + 8u * L.rs + 4u * L.tail;
     L.stride = std::max(16u, (used + 15u) & ~15u);
+    if (const char* e = getenv("IDIST_ROW_ALIGN_FLOATS")) {   // experiment knob: pad rows to a coarser boundary
+        const uint32_t al = (uint32_t)atoi(e);
+        if (al >= 16 && (al & (al - 1)) == 0) L.stride = (L.stride + al - 1) & ~(al - 1);
+    }
     return L;
 }
 
@@ -283,7 +287,7 @@ idist_status run_build(idist_index* ix) {
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave (> 64 KiB)", smem);
 
     // step B tile: as many selected rows on chip as fit 64 KiB of LDS next to 8 staging slots
-    uint32_t rt = 16;
+    uint32_t rt = 8;
     if (const char* e = getenv("IDIST_BUILD_RT")) rt = (uint32_t)atoi(e);
     while (rt > 0 && smem_bytes_update(ix->L.nb, rt) > 64 * 1024) rt--;
     const size_t smemB = smem_bytes_update(ix->L.nb, rt);
@@ -292,13 +296,14 @@ idist_status run_build(idist_index* ix) {
     uint8_t *d_vis = nullptr, *d_gen = nullptr;
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
-    uint32_t* d_small = nullptr;           // [0] n_touched, [1..2] queue, [3] status
+    uint32_t* d_small = nullptr;           // [0] n_touched, [1..4] queue (A, B, n_slow, B2), [5] status
+    uint32_t *d_row_nsel = nullptr, *d_slow = nullptr;
     unsigned long long* d_stats = nullptr; // [8]
     const size_t n_edges = (size_t)cap * IDIST_M2;
     const size_t n_touch = std::min<size_t>(n_edges, n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto release = [&]() {
-        hipFree(d_nbr_dist);
+        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow);
         hipFree(d_vis); hipFree(d_gen); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
         if (e0) hipEventDestroy(e0);
@@ -318,6 +323,9 @@ idist_status run_build(idist_index* ix) {
     BCHK(hipMemset(d_gen, 0, std::max<size_t>(slots, 256)));
     BCHK(hipMalloc((void**)&d_nbr_dist, (size_t)n * IDIST_M2 * 4));
     BCHK(hipMemset(d_nbr_dist, 0, (size_t)n * IDIST_M2 * 4));
+    BCHK(hipMalloc((void**)&d_row_nsel, (size_t)n * 4));
+    BCHK(hipMemset(d_row_nsel, 0, (size_t)n * 4));
+    BCHK(hipMalloc((void**)&d_slow, n_touch * 4));
     BCHK(hipMalloc((void**)&d_edge_pid, n_edges * 4));
     BCHK(hipMalloc((void**)&d_edge_dist, n_edges * 4));
     BCHK(hipMalloc((void**)&d_next, n_edges * 4));
@@ -346,10 +354,15 @@ idist_status run_build(idist_index* ix) {
     a.next = d_next;
     a.touched = d_touched;
     a.nbr_dist = d_nbr_dist;
+    a.row_nsel = d_row_nsel;
+    a.slow = d_slow;
     a.rt = rt;
     a.n_touched = d_small;
     a.queue = d_small + 1;
-    a.status = d_small + 3;
+    a.n_slow = d_small + 3;      // == &queue[2]
+    a.status = d_small + 5;
+    const size_t smemF = smem_bytes_update_fast(ix->L.stride);
+    const bool no_fast = getenv("IDIST_BUILD_NO_FAST") != nullptr;   // test knob: route every update through B2
     a.stats = d_stats;
 
     uint32_t cum[IDIST_MAX_LAYERS + 1];
@@ -371,15 +384,21 @@ idist_status run_build(idist_index* ix) {
             B = std::min(B, end - g);
             a.start = g;
             a.count = B;
-            BCHK(hipMemsetAsync(d_small, 0, 12, stream));   // n_touched + both queue heads
+            BCHK(hipMemsetAsync(d_small, 0, 20, stream));   // n_touched, queue heads, n_slow
             const uint32_t gridA = std::min(B, slots);
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
+            const uint32_t gridS = std::min<uint32_t>(gridB, (uint32_t)ix->n_cu * 6);
+            a.efc = no_fast ? 0u : cfg.ef_construction;   // efc = 0 makes the fast kernel defer everything
+            BuildArgs af = a;
+            a.efc = cfg.ef_construction;
 #define LAUNCH_BUILD(NB_, RS_, TAIL_)                                                              \
     {                                                                                              \
         auto kA = build_insert_kernel<NB_, RS_, TAIL_>;                                            \
+        auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         IDIST_LAUNCH(kA, gridA, 64, smem, stream, view, a);                                        \
-        IDIST_LAUNCH(kB, gridB, 64, smemB, stream, view, a);                                       \
+        IDIST_LAUNCH(kF, gridB, 64, smemF, stream, view, af);                                      \
+        IDIST_LAUNCH(kB, gridS, 64, smemB, stream, view, a);                                       \
     }
             IDIST_DISPATCH(ix->L, LAUNCH_BUILD);
 #undef LAUNCH_BUILD
@@ -398,9 +417,9 @@ idist_status run_build(idist_index* ix) {
     BCHK(hipEventSynchronize(e1));
     float ms = 0;
     BCHK(hipEventElapsedTime(&ms, e0, e1));
-    uint32_t small[4] = {0, 0, 0, 0};
+    uint32_t small[8] = {0};
     unsigned long long stats[8] = {0};
-    BCHK(hipMemcpy(small, d_small, 16, hipMemcpyDeviceToHost));
+    BCHK(hipMemcpy(small, d_small, 32, hipMemcpyDeviceToHost));
     BCHK(hipMemcpy(stats, d_stats, 64, hipMemcpyDeviceToHost));
 #undef BCHK
     release();
@@ -412,7 +431,9 @@ idist_status run_build(idist_index* ix) {
     ix->stats.n_updates = stats[5];
     ix->stats.n_batches = n_batches;
     ix->stats.seconds = ms * 1e-3;
-    return device_status_to_code(small[3]);
+    ix->stats.n_updates_fast = stats[6];
+    ix->stats.n_updates_full = stats[7];
+    return device_status_to_code(small[5]);
 }
 
 idist_status build_common(const void* points, bool on_device, uint32_t n, uint32_t dim, const idist_config* cfg,

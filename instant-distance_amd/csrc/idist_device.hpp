@@ -385,7 +385,7 @@ struct HeurCounters { uint32_t n_dist, n_rows; };
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ int select_heuristic(const IndexView& ix, const uint64_t* Wsrc, int nw, bool keep_pruned,
                                                 float* cq, uint64_t* sel, uint64_t* disc, uint32_t* act_pid,
-                                                uint32_t* act_dist, HeurCounters& hc) {
+                                                uint32_t* act_dist, HeurCounters& hc, int& n_selected) {
     const int lane = lane_id();
     int nsel = 0, ndis = 0;
     for (int wi = 0; wi < nw; wi++) {                      // :668
@@ -419,6 +419,7 @@ __device__ __forceinline__ int select_heuristic(const IndexView& ix, const uint6
         if (!pruned) nsel++; else ndis++;
         wave_sync();
     }
+    n_selected = nsel;
     if (keep_pruned) {                                     // :687-695
         int take = kM2 - nsel;
         if (take > ndis) take = ndis;
@@ -569,7 +570,7 @@ __device__ __forceinline__ bool tile_any_closer(const IndexView& ix, const Tile&
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ int select_heuristic_tiled(const IndexView& ix, const uint64_t* Wsrc, int nw, bool keep_pruned,
                                                       const Tile& t, uint64_t* sel, uint64_t* disc, uint32_t* act_pid,
-                                                      uint32_t* act_dist, HeurCounters& hc) {
+                                                      uint32_t* act_dist, HeurCounters& hc, int& n_selected) {
     const int lane = lane_id();
     const int nb = NB >= 0 ? NB : (int)ix.nb;
     int nsel = 0, ndis = 0;
@@ -612,6 +613,7 @@ __device__ __forceinline__ int select_heuristic_tiled(const IndexView& ix, const
             wave_sync();
         }
     }
+    n_selected = nsel;
     if (keep_pruned) {                                               // :687-695
         if (ndis > kM2) ndis = kM2;
         int take = kM2 - nsel;

@@ -285,8 +285,11 @@ struct BuildArgs {
     uint32_t* touched;          // distinct nodes with a non-empty inbox
     uint32_t* n_touched;
     uint32_t* nbr_dist;         // [n][64] distance bits of every zero-row entry to its owner (build scratch)
-    uint32_t rt;                // step B: selected rows kept in the LDS tile
-    uint32_t* queue;            // work queue heads: [0] step A, [1] step B
+    uint32_t* row_nsel;         // [n] how many leading entries of a zero row were SELECTED (the rest is back-fill)
+    uint32_t* slow;             // nodes whose update needs the full re-selection (step B2)
+    uint32_t* n_slow;
+    uint32_t rt;                // step B2: selected rows kept in the LDS tile
+    uint32_t* queue;            // work queue heads: [0] step A, [1] step B, [3] step B2 ([2] = n_slow)
     unsigned long long* stats;  // [8] n_dist n_exp0 n_expU n_heur_dist n_heur_rows n_updates
     uint32_t* status;
 };
@@ -335,8 +338,10 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
             }
         }
         const int nw = st.plen < st.ef ? st.plen : st.ef;             // Search.nearest
+        int n_selected = 0;
         const int nsel = select_heuristic<NB, RS, TAIL>(ix, st.W, nw, a.keep_pruned != 0, sm.cq, sel, disc,
-                                                        sm.act_pid, sm.act_dist, hc);  // :470-472
+                                                        sm.act_pid, sm.act_dist, hc, n_selected);  // :470-472
+        if (lane == 0) a.row_nsel[nw_pid] = (uint32_t)n_selected;
         // node.set(i, pid) for every found neighbour (:516); the row was all-INVALID
         ix.zero[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
         a.nbr_dist[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)(sel[lane] >> 32) : 0u;
@@ -367,6 +372,182 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
 }
 
 // ---------------------------------------------------------------------------
+// Build step B (fast path): memoised re-selection.
+//
+// select_heuristic (core/lib.rs:636-698) walks its candidates nearest-first and the
+// verdict on a candidate depends only on the candidates SELECTED before it.  Every zero
+// row this builder writes has the form [selected, ascending | back-filled discarded,
+// ascending] and row_nsel keeps the split.  A discarded candidate never influences
+// anyone, so re-running the selection on {row} U {new points} gives every old entry in
+// front of the first new point its old verdict, and afterwards
+//   * an old SELECTED entry can only be newly pruned by members ADDED since (it already
+//     passed every older selected member that precedes it),
+//   * an old DISCARDED entry stays discarded as long as no older selected member has
+//     been removed (its pruner is still there),
+//   * a new point is checked against the current selected set.
+// All distances that can matter therefore involve a new point: one gather of
+// {old selected} U {new} rows per new point (~20 rows) instead of ~800 pairwise
+// distances.  If an old selected entry does get pruned and an old discarded entry
+// follows (a cascade), or more than kMaxNewFast points arrive, the node is handed to the
+// full re-selection (step B2, build_update_kernel).  Results are identical by
+// construction; tests/test_parity.py checks byte-identity with the oracle.
+// ---------------------------------------------------------------------------
+constexpr int kUpdW = 136;   // <= 64 current + 64 new + slack
+constexpr int kMaxNewFast = 8;
+constexpr int kFastX = 80;   // columns of the new-vs-{old selected, new} distance table
+__host__ __device__ inline size_t smem_bytes_update_fast(uint32_t stride) {
+    return (size_t)stride * 4 + (size_t)(kUpdW + 72 + 64 + 64 + 64) * 8 +
+           (size_t)(kUpdW + kFastX + kMaxNewFast * kFastX + 64 + kMaxNewFast) * 4;
+}
+
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, BuildArgs a) {
+    IDIST_DYN_SMEM(smem_raw);
+    float* cq = reinterpret_cast<float*>(smem_raw);
+    uint64_t* W = reinterpret_cast<uint64_t*>(cq + ix.stride);
+    uint64_t* news = W + kUpdW;
+    uint64_t* sel = news + 72;
+    uint64_t* disc = sel + 64;
+    uint64_t* curk = disc + 64;
+    uint32_t* kindx = reinterpret_cast<uint32_t*>(curk + 64);   // kUpdW: kind << 8 | x
+    uint32_t* X = kindx + kUpdW;                                // kFastX pids: old selected, then new
+    uint32_t* Dn = X + kFastX;                                  // [kMaxNewFast][kFastX] distance bits
+    uint32_t* Rx = Dn + kMaxNewFast * kFastX;                   // x of every member of R
+    uint32_t* addx = Rx + 64;                                   // new points that entered R
+    enum : uint32_t { OLD_SEL = 0, OLD_DISC = 1, NEW = 2 };
+    const int lane = lane_id();
+    const uint32_t ntouched = *a.n_touched;
+    HeurCounters hc{0, 0};
+    uint32_t updates = 0, deferred = 0, status = 0;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&a.queue[1], 1u);
+        t = uniform_u32(t);
+        if (t >= ntouched) break;
+        const uint32_t pid = a.touched[t];
+        wave_sync();
+        // the new points that chose `pid` (inbox), nearest first
+        WState ns{news, 0, kM2, 0, 0u};
+        uint32_t e = a.head[pid];
+        uint32_t guard = 0;
+        while (e != kInvalid) {
+            const uint64_t k = ((uint64_t)a.edge_dist[e] << 32) | (a.start + e / kM2);
+            const int idx = w_rank(ns, k);
+            if (idx < ns.ef) w_insert(ns, idx, k);
+            if (ns.plen > ns.ef) ns.plen = ns.ef;
+            e = a.next[e];
+            if (++guard > a.count) { status |= kStGuard; break; }
+        }
+        const int k_new = ns.plen;
+        const uint32_t cur = ix.zero[(size_t)pid * kM2 + lane];
+        const uint32_t curd = a.nbr_dist[(size_t)pid * kM2 + lane];
+        const int ns0 = (int)a.row_nsel[pid];
+        const uint64_t inval = __ballot(cur == kInvalid);
+        const int ncur = inval ? __builtin_ctzll(inval) : 64;
+        const uint64_t key = lane < ncur ? (((uint64_t)curd << 32) | cur) : kMaxKey;
+        const int total = ncur + k_new;
+        bool defer = k_new > kMaxNewFast || total > (int)a.efc || guard > a.count;
+        int nR = 0, nD = 0;
+        if (!defer) {
+            // candidates = sort(current U new) — nothing can be dropped by `idx < ef` (total <= ef)
+            if (lane < ncur) curk[lane] = key;
+            if (lane < ns0) X[lane] = cur;
+            if (lane < k_new) X[ns0 + lane] = (uint32_t)news[lane];
+            wave_sync();
+            const uint64_t keyb = lane < k_new ? (news[lane] & kKeyMask) : kMaxKey;
+            int ra = 0, rb = lane;
+            for (int i = 0; i < ncur; i++) {
+                const uint64_t o = curk[i];
+                ra += o < key ? 1 : 0;
+                rb += o < keyb ? 1 : 0;
+            }
+            for (int i = 0; i < k_new; i++) ra += (news[i] & kKeyMask) < key ? 1 : 0;
+            if (lane < ncur) { W[ra] = key; kindx[ra] = lane < ns0 ? ((OLD_SEL << 8) | (uint32_t)lane) : (OLD_DISC << 8); }
+            if (lane < k_new) { W[rb] = keyb; kindx[rb] = (NEW << 8) | (uint32_t)(ns0 + lane); }
+            wave_sync();
+            // distances of every new point to {old selected} U {new}  (Point::distance is symmetric bit for bit)
+            const int nx = ns0 + k_new;
+            for (int ai = 0; ai < k_new; ai++) {
+                const float* prow = ix.points + (size_t)(uint32_t)news[ai] * ix.stride;
+                for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+                    *reinterpret_cast<float4*>(cq + o) = *reinterpret_cast<const float4*>(prow + o);
+                wave_sync();
+                dist_rounds<NB, RS, TAIL>(ix, cq, X, Dn + ai * kFastX, nx);
+                wave_sync();
+                hc.n_dist += (uint32_t)nx;
+                hc.n_rows += 1;
+            }
+            // replay of select_heuristic (core/lib.rs:668-685) on stored verdicts
+            int nAdd = 0;
+            bool removed = false;
+            for (int i = 0; i < total; i++) {
+                if (nR >= kM2) break;                                   // :669-671
+                const uint64_t c = W[i];
+                const uint32_t kx = kindx[i];
+                const uint32_t kind = kx >> 8, x = kx & 255u;
+                const uint32_t cd = (uint32_t)(c >> 32);
+                bool pruned;
+                if (kind == OLD_SEL) {
+                    bool closer = false;
+                    if (lane < nAdd) closer = Dn[addx[lane] * kFastX + x] < cd;          // strict <, :678
+                    pruned = __ballot(closer) != 0ull;
+                    if (pruned) removed = true;
+                } else if (kind == OLD_DISC) {
+                    if (removed) { defer = true; break; }               // its pruner may be gone: full re-selection
+                    pruned = true;
+                } else {
+                    bool closer = false;
+                    if (lane < nR) closer = Dn[(x - (uint32_t)ns0) * kFastX + Rx[lane]] < cd;
+                    pruned = __ballot(closer) != 0ull;
+                }
+                wave_sync();
+                if (lane == 0) {
+                    if (!pruned) {
+                        sel[nR] = c;
+                        Rx[nR] = x;
+                        if (kind == NEW) addx[nAdd] = x - (uint32_t)ns0;
+                    } else if (nD < kM2) {
+                        disc[nD] = c;
+                    }
+                }
+                if (!pruned) { nR++; if (kind == NEW) nAdd++; } else { nD++; }
+                wave_sync();
+            }
+        }
+        if (defer) {
+            // leave the inbox in place; step B2 redoes this node from scratch
+            if (lane == 0) a.slow[atomicAdd(a.n_slow, 1u)] = pid;
+            deferred++;
+            wave_sync();
+            continue;
+        }
+        if (lane == 0) { a.head[pid] = kInvalid; a.row_nsel[pid] = (uint32_t)nR; }
+        int nsel = nR;
+        if (a.keep_pruned) {                                            // :687-695
+            if (nD > kM2) nD = kM2;
+            int take = kM2 - nsel;
+            if (take > nD) take = nD;
+            if (lane < take) sel[nsel + lane] = disc[lane];
+            if (take > 0) nsel += take;
+            wave_sync();
+        }
+        ix.zero[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;     // ZeroNode::rewrite
+        a.nbr_dist[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)(sel[lane] >> 32) : 0u;
+        updates++;
+        wave_sync();
+    }
+    if (lane == 0) {
+        if (status) atomicOr(a.status, status);
+        if (updates | deferred) {
+            atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
+            atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);
+            atomicAdd(&a.stats[5], (unsigned long long)updates);
+            atomicAdd(&a.stats[6], (unsigned long long)updates);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Build step B: for every node that was selected by at least one new point,
 // Search::add_neighbor_heuristic + ZeroNode::rewrite (core/lib.rs:485-496,
 // :616-631; core/types.rs:88-98).  With one new point per step this is the
@@ -378,7 +559,6 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
 // is symmetric), candidate rows are fetched 8 at a time into an LDS tile, and
 // the selected set stays in that tile, so every row crosses HBM once per update.
 // ---------------------------------------------------------------------------
-constexpr int kUpdW = 136;   // <= 64 current + 64 new + slack
 __host__ __device__ inline size_t smem_bytes_update(uint32_t nb, uint32_t rt) {
     return tile_floats(nb, rt + 8) * 4 + (size_t)(kUpdW + 72 + 64 + 64 + 64) * 8 + 2 * 64 * 4;
 }
@@ -401,15 +581,15 @@ __global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArg
     uint32_t* act_pid = reinterpret_cast<uint32_t*>(curk + 64);
     uint32_t* act_dist = act_pid + 64;
     const int lane = lane_id();
-    const uint32_t ntouched = *a.n_touched;
+    const uint32_t nslow = *a.n_slow;
     HeurCounters hc{0, 0};
     uint32_t updates = 0, status = 0;
     for (;;) {
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&a.queue[1], 1u);
+        if (lane == 0) t = atomicAdd(&a.queue[3], 1u);
         t = uniform_u32(t);
-        if (t >= ntouched) break;
-        const uint32_t pid = a.touched[t];
+        if (t >= nslow) break;
+        const uint32_t pid = a.slow[t];
         wave_sync();
         // drain the inbox: keep the <= 64 nearest new points (a node holds 64 links at most)
         WState ns{news, 0, kM2, 0, 0u};
@@ -464,8 +644,10 @@ __global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArg
             }
         }
         // select_heuristic over ALL of `nearest` (no truncate in add_neighbor_heuristic, :630)
+        int n_selected = 0;
         const int nsel = select_heuristic_tiled<NB, RS, TAIL>(ix, st.W, st.plen, a.keep_pruned != 0, tile, sel, disc,
-                                                              act_pid, act_dist, hc);
+                                                              act_pid, act_dist, hc, n_selected);
+        if (lane == 0) a.row_nsel[pid] = (uint32_t)n_selected;
         // ZeroNode::rewrite (core/types.rs:88-98): rows are prefix-valid, so clearing to the end is identical
         ix.zero[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
         a.nbr_dist[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)(sel[lane] >> 32) : 0u;
@@ -478,6 +660,7 @@ __global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArg
             atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
             atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);
             atomicAdd(&a.stats[5], (unsigned long long)updates);
+            atomicAdd(&a.stats[7], (unsigned long long)updates);
         }
     }
 }
