@@ -112,9 +112,6 @@ idist_status validate_config(const idist_config* cfg, bool for_build) {
     if (for_build) {
         if (cfg->ef_construction == 0 || cfg->ef_construction > IDIST_MAX_EF)
             return fail(IDIST_ERR_INVALID_ARG, "ef_construction %u out of [1,%u]", cfg->ef_construction, IDIST_MAX_EF);
-        if (!cfg->has_heuristic)
-            return fail(IDIST_ERR_UNSUPPORTED,
-                        "select_heuristic(None) (core/lib.rs:466-469,497-515) is not implemented on the GPU engine");
         if (cfg->extend_candidates)
             return fail(IDIST_ERR_UNSUPPORTED,
                         "Heuristic::extend_candidates=true is not implemented (it deadlocks in the reference: "
@@ -345,6 +342,7 @@ idist_status run_build(idist_index* ix) {
     a.efc = cfg.ef_construction;
     a.wcap = wcap;
     a.keep_pruned = cfg.keep_pruned ? 1u : 0u;
+    a.has_heuristic = cfg.has_heuristic ? 1u : 0u;
     a.visited = d_vis;
     a.vis_stride = vis_stride;
     a.gen = d_gen;
@@ -396,9 +394,14 @@ idist_status run_build(idist_index* ix) {
         auto kA = build_insert_kernel<NB_, RS_, TAIL_>;                                            \
         auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
+        auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
         IDIST_LAUNCH(kA, gridA, 64, smem, stream, view, a);                                        \
-        IDIST_LAUNCH(kF, gridB, 64, smemF, stream, view, af);                                      \
-        IDIST_LAUNCH(kB, gridS, 64, smemB, stream, view, a);                                       \
+        if (cfg.has_heuristic) {                                                                   \
+            IDIST_LAUNCH(kF, gridB, 64, smemF, stream, view, af);                                  \
+            IDIST_LAUNCH(kB, gridS, 64, smemB, stream, view, a);                                   \
+        } else {                                                                                   \
+            IDIST_LAUNCH(kP, gridB, 64, (size_t)(72 * 8 + 64 * 4), stream, view, a);               \
+        }                                                                                          \
     }
             IDIST_DISPATCH(ix->L, LAUNCH_BUILD);
 #undef LAUNCH_BUILD

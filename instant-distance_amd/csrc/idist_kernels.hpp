@@ -275,6 +275,7 @@ struct BuildArgs {
     uint32_t layer, top;        // LayerId of this range / of the top layer
     uint32_t efc, wcap;
     uint32_t keep_pruned;
+    uint32_t has_heuristic;     // 0 = Builder::select_heuristic(None): select_simple + sorted splice
     uint8_t* visited;           // [slots][vis_stride]
     size_t vis_stride;
     uint8_t* gen;               // [slots]
@@ -339,8 +340,16 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
         }
         const int nw = st.plen < st.ef ? st.plen : st.ef;             // Search.nearest
         int n_selected = 0;
-        const int nsel = select_heuristic<NB, RS, TAIL>(ix, st.W, nw, a.keep_pruned != 0, sm.cq, sel, disc,
-                                                        sm.act_pid, sm.act_dist, hc, n_selected);  // :470-472
+        int nsel;
+        if (a.has_heuristic) {
+            nsel = select_heuristic<NB, RS, TAIL>(ix, st.W, nw, a.keep_pruned != 0, sm.cq, sel, disc,
+                                                  sm.act_pid, sm.act_dist, hc, n_selected);  // :470-472
+        } else {                                                      // select_simple, :466-469, :758-760
+            nsel = nw < kM2 ? nw : kM2;
+            if (lane < nsel) sel[lane] = st.W[lane] & kKeyMask;
+            n_selected = nsel;
+            wave_sync();
+        }
         if (lane == 0) a.row_nsel[nw_pid] = (uint32_t)n_selected;
         // node.set(i, pid) for every found neighbour (:516); the row was all-INVALID
         ix.zero[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
@@ -368,6 +377,79 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
             atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
             atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Build step B for Builder::select_heuristic(None) (core/lib.rs:497-515): splice the new
+// point into each selected neighbour's row at the index Rust's slice::binary_search_by
+// returns for the reference's comparator — which is REVERSED (it returns
+// target.cmp(element), :510, and Greater for an empty slot, :505-508), so the result is
+// whatever std's probe sequence makes of it.  Restated literally (Rust >= 1.82 branch-free
+// form); d(points[pid], points[third]) comes from the stored nbr_dist.  ZeroNode::insert:
+// core/types.rs:100-113.  Several new points for one node are applied in PointId order.
+// ---------------------------------------------------------------------------
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(64) void build_update_simple_kernel(IndexView ix, BuildArgs a) {
+    IDIST_DYN_SMEM(smem_raw);
+    uint64_t* news = reinterpret_cast<uint64_t*>(smem_raw);     // 72: key = edge index (ascending = PointId order)
+    int* cmps = reinterpret_cast<int*>(news + 72);              // 64
+    const int lane = lane_id();
+    const uint32_t ntouched = *a.n_touched;
+    uint32_t updates = 0, status = 0;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&a.queue[1], 1u);
+        t = uniform_u32(t);
+        if (t >= ntouched) break;
+        const uint32_t pid = a.touched[t];
+        wave_sync();
+        WState ns{news, 0, kM2, 0, 0u};
+        uint32_t e = a.head[pid];
+        uint32_t guard = 0;
+        while (e != kInvalid) {
+            const uint64_t k = (uint64_t)e;
+            const int idx = w_rank(ns, k);
+            if (idx < ns.ef) w_insert(ns, idx, k);
+            if (ns.plen > ns.ef) ns.plen = ns.ef;
+            e = a.next[e];
+            if (++guard > a.count) { status |= kStGuard; break; }
+        }
+        if (lane == 0) a.head[pid] = kInvalid;
+        uint32_t id = ix.zero[(size_t)pid * kM2 + lane];
+        uint32_t dd = a.nbr_dist[(size_t)pid * kM2 + lane];
+        for (int i = 0; i < ns.plen; i++) {
+            const uint32_t ei = (uint32_t)news[i];
+            const uint32_t nw_pid = a.start + ei / kM2;
+            const uint32_t target = a.edge_dist[ei];              // `distance` = d(new, pid), :483
+            wave_sync();
+            // f(third): empty -> Greater (:505-508), else distance.cmp(d(old, third)) (:510)
+            cmps[lane] = id == kInvalid ? 1 : (target > dd) - (target < dd);
+            wave_sync();
+            int size = kM2, base = 0;                              // slice::binary_search_by
+            while (size > 1) {
+                const int half = size / 2, mid = base + half;
+                base = cmps[mid] > 0 ? base : mid;
+                size -= half;
+            }
+            const int c = cmps[base];
+            const int idx = c == 0 ? base : base + (c < 0 ? 1 : 0);   // .unwrap_or_else(|e| e), :512
+            if (idx < kM2) {                                       // ZeroNode::insert, core/types.rs:100-113
+                const bool occupied = bcast_u32(id, idx) != kInvalid;
+                const uint32_t pid_l = bcast_u32(id, lane > 0 ? lane - 1 : 0);
+                const uint32_t dd_l = bcast_u32(dd, lane > 0 ? lane - 1 : 0);
+                if (occupied && lane > idx) { id = pid_l; dd = dd_l; }     // copy_within(idx..63, idx+1)
+                if (lane == idx) { id = nw_pid; dd = target; }
+            }
+        }
+        ix.zero[(size_t)pid * kM2 + lane] = id;
+        a.nbr_dist[(size_t)pid * kM2 + lane] = dd;
+        updates++;
+        wave_sync();
+    }
+    if (lane == 0) {
+        if (status) atomicOr(a.status, status);
+        if (updates) atomicAdd(&a.stats[5], (unsigned long long)updates);
     }
 }
 

@@ -78,9 +78,13 @@ int main(int argc, char** argv) {
     size_t recall = randomized(Builder::default_(), 123456789ull, n);
     printf("heuristic recall = %zu\n", recall);
     REQUIRE(recall > 97);                          // tests/all.rs:45
-    // select_heuristic(None) is reported, not silently mis-built (tests/all.rs:48-53)
+    size_t recall_simple = randomized(Builder::default_().select_heuristic(nullptr), 987654321ull, n);
+    printf("simple recall = %zu\n", recall_simple);
+    REQUIRE(recall_simple > 90);                   // tests/all.rs:52
+    // extend_candidates = true deadlocks in the reference; reported, not silently mis-built
     try {
-        randomized(Builder::default_().select_heuristic(nullptr), 1, 64);
+        Heuristic h{true, true};
+        randomized(Builder::default_().select_heuristic(&h), 1, 64);
         REQUIRE(false);
     } catch (const Error& e) { REQUIRE(e.status == IDIST_ERR_UNSUPPORTED); }
     // examples/colors.rs

@@ -87,14 +87,16 @@ def check_search_parity(ida, oracle, n, dim, ef_search=100, metric=0, kind="unif
     return h, oix
 
 
-def check_build_exact(ida, oracle, n, dim, metric=0, kind="uniform", ef_construction=100, keep_pruned=True, seed=0):
+def check_build_exact(ida, oracle, n, dim, metric=0, kind="uniform", ef_construction=100, keep_pruned=True, seed=0,
+                      heuristic=True):
     """max_batch = 1: zero/layers byte-identical to the oracle's sequential build."""
     rng = np.random.default_rng(seed)
     pts = gen_points(rng, n, dim, kind)
-    cfg = oracle.default_config(metric=metric, ef_construction=ef_construction, keep_pruned=int(keep_pruned))
+    cfg = oracle.default_config(metric=metric, ef_construction=ef_construction, keep_pruned=int(keep_pruned),
+                                has_heuristic=int(heuristic))
     oix = oracle.Index.build(pts, cfg, threads=1)
     b = (ida.Builder().metric(metric).max_batch(1).ef_construction(ef_construction)
-         .select_heuristic(ida.Heuristic(False, keep_pruned)))
+         .select_heuristic(ida.Heuristic(False, keep_pruned) if heuristic else None))
     h = ida.Hnsw.from_ordered_points(pts, b)
     zero, layers = h.into_parts()
     assert np.array_equal(zero, oix.zero)

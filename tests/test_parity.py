@@ -76,6 +76,8 @@ def test_search_on_parallel_built_graph(eng, oracle):
     (1, 4, {}), (2, 4, {}), (5, 2, {"metric": 1}), (33, 3, {}), (100, 2, {"metric": 1}),
     (150, 12, {}), (120, 300, {}), (140, 8, {"ef_construction": 20}), (130, 5, {"keep_pruned": False}),
     (140, 3, {"kind": "grid", "metric": 1}),
+    (150, 6, {"heuristic": False}), (120, 2, {"heuristic": False, "metric": 1}), (100, 300, {"heuristic": False}),
+    (130, 3, {"heuristic": False, "kind": "grid", "metric": 1}),
 ])
 def test_build_exact_small(eng, oracle, n, dim, kw):
     ida, kind = eng
@@ -83,10 +85,59 @@ def test_build_exact_small(eng, oracle, n, dim, kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,dim", [(1024, 2), (3000, 128), (2000, 300), (1200, 768)])
-def test_build_exact_gpu(engine_loader, oracle, n, dim):
+@pytest.mark.parametrize("n,dim,heur", [(1024, 2, True), (3000, 128, True), (2000, 300, True), (1200, 768, True),
+                                        (1024, 2, False), (3000, 128, False), (1500, 300, False)])
+def test_build_exact_gpu(engine_loader, oracle, n, dim, heur):
     ida = engine_loader("gpu")
-    pc.check_build_exact(ida, oracle, n=n, dim=dim, seed=n)
+    pc.check_build_exact(ida, oracle, n=n, dim=dim, seed=n, heuristic=heur)
+
+
+@pytest.mark.gpu
+def test_c1_isize_points_plumbing_gpu(engine_loader, oracle):
+    """BASELINE config C1: 1k x 3-d isize points (README/colors.rs Point), k = 1.  isize coordinates in
+    [0,255] are exact in f32, so the GPU engine answers it bit for bit like the reference's CPU path."""
+    ida = engine_loader("gpu")
+    rng = np.random.default_rng(1)
+    pts = rng.integers(0, 256, size=(1000, 3)).astype(np.float32)
+    q = rng.integers(0, 256, size=(200, 3)).astype(np.float32)
+    h = pc.check_build_exact(ida, oracle, n=1000, dim=3, metric=1, seed=1, kind="uniform")  # same path, float data
+    b = ida.Builder().metric(ida.METRIC_L2).max_batch(1)
+    hi = ida.Hnsw.from_ordered_points(pts, b)
+    oix = oracle.Index.build(pts, oracle.default_config(metric=1))
+    assert np.array_equal(hi.into_parts()[0], oix.zero)
+    got, want = hi.search_batch(q, ida.Search()), oix.search(q)
+    assert np.array_equal(got.pid[:, 0], want.pid[:, 0])                       # k = 1
+    assert np.array_equal(pc.bits(got.distance), pc.bits(want.dist))
+    truth, td = hi.bruteforce(q, 1)
+    assert np.mean(pc.bits(got.distance[:, 0]) == pc.bits(td[:, 0])) > 0.97    # nearest found (distance ties allowed)
+
+
+@pytest.mark.gpu
+def test_c2_full_size_properties_gpu(engine_loader, oracle):
+    """BASELINE config C2 at full size (100k x 128 f32, k = 10, ef_search = 100): the oracle cannot
+    build this in seconds, so check size-independent properties + oracle search parity on the
+    GPU-built graph (the graph is an input of Hnsw::search)."""
+    ida = engine_loader("gpu")
+    rng = np.random.default_rng(2)
+    pts = rng.random((100_000, 128), dtype=np.float32)
+    q = rng.random((2000, 128), dtype=np.float32)
+    q[:100] = pts[:100]
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder())
+    got = h.search_batch(q, ida.Search(), counters=True)
+    assert np.all(got.count == 100)
+    assert np.all(got.distance[:, :-1] <= got.distance[:, 1:])                 # sortedness
+    assert np.array_equal(got.pid[:100, 0], np.arange(100))                    # self query, distance 0
+    assert np.all(got.distance[:100, 0] == 0)
+    again = h.search_batch(q, ida.Search())
+    assert np.array_equal(again.pid, got.pid)                                  # idempotence
+    zero, layers = h.into_parts()
+    assert [l.shape[0] for l in layers] == oracle.layer_sizes(100_000)[1:]
+    oix = oracle.Index.from_arrays(pts, zero, layers, oracle.default_config())
+    want = oix.search(q[:500], threads=8)
+    assert np.array_equal(got.pid[:500], want.pid) and np.array_equal(got.counters[:500], want.counters)
+    assert np.array_equal(pc.bits(got.distance[:500]), pc.bits(want.dist))
+    truth, _ = h.bruteforce(q[:300], 10)
+    assert pc.recall_at(got.pid[:300], truth, 10) > 0.5       # uniform 128-d data: high intrinsic dimension
 
 
 def test_build_batched(eng, oracle):
@@ -177,6 +228,9 @@ def test_import_validation_and_unsupported(eng, oracle):
     with pytest.raises(ida.IdistError) as e:
         ida.Builder().ef_search(5000).build_hnsw(pts)
     assert e.value.status == 1
+    # select_heuristic(None) builds (the "simple" path of core/lib.rs:497-515)
+    h, _ = ida.Builder().select_heuristic(None).seed(3).build_hnsw(pts)
+    assert len(list(h.search(pts[0], ida.Search()))) == 50
 
 
 def test_permutation_matches_oracle_restatement(eng, oracle):

@@ -3,7 +3,7 @@
 (tests/simt), `-m gpu` run uses the MI355X.
 
   instant-distance/tests/all.rs:11-39   map
-  instant-distance/tests/all.rs:41-88   random_heuristic (random_simple: GPU engine reports UNSUPPORTED)
+  instant-distance/tests/all.rs:41-88   random_heuristic, random_simple
   instant-distance/examples/colors.rs   nearest colour
   instant-distance-py/test/test.py      self query on 1024 x 300
 """
@@ -55,11 +55,10 @@ def test_random_heuristic(ida, sizes):
     assert recall > 97, recall            # tests/all.rs:45
 
 
-def test_random_simple_is_reported_unsupported(ida):
-    # Builder::select_heuristic(None), tests/all.rs:48-53: not implemented on the GPU engine — loud error
-    with pytest.raises(ida.IdistError) as e:
-        ida.Builder.default().select_heuristic(None).build_hnsw(np.zeros((10, 2), np.float32))
-    assert e.value.status == 4
+def test_random_simple(ida, sizes):
+    n = sizes["random_n"]
+    recall = _randomized(ida, ida.Builder.default().select_heuristic(None), 987654321, n)
+    assert recall > 90, recall            # tests/all.rs:52
 
 
 def test_colors(ida):
