@@ -294,13 +294,13 @@ idist_status run_build(idist_index* ix) {
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
     uint32_t* d_small = nullptr;           // [0] n_touched, [1..4] queue (A, B, n_slow, B2), [5] status
-    uint32_t *d_row_nsel = nullptr, *d_slow = nullptr;
+    uint32_t *d_row_nsel = nullptr, *d_slow = nullptr, *d_nbr_aux = nullptr;
     unsigned long long* d_stats = nullptr; // [8]
     const size_t n_edges = (size_t)cap * IDIST_M2;
     const size_t n_touch = std::min<size_t>(n_edges, n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto release = [&]() {
-        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow);
+        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux);
         hipFree(d_vis); hipFree(d_gen); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
         if (e0) hipEventDestroy(e0);
@@ -320,6 +320,8 @@ idist_status run_build(idist_index* ix) {
     BCHK(hipMemset(d_gen, 0, std::max<size_t>(slots, 256)));
     BCHK(hipMalloc((void**)&d_nbr_dist, (size_t)n * IDIST_M2 * 4));
     BCHK(hipMemset(d_nbr_dist, 0, (size_t)n * IDIST_M2 * 4));
+    BCHK(hipMalloc((void**)&d_nbr_aux, (size_t)n * IDIST_M2 * 4));
+    BCHK(hipMemset(d_nbr_aux, 0, (size_t)n * IDIST_M2 * 4));
     BCHK(hipMalloc((void**)&d_row_nsel, (size_t)n * 4));
     BCHK(hipMemset(d_row_nsel, 0, (size_t)n * 4));
     BCHK(hipMalloc((void**)&d_slow, n_touch * 4));
@@ -353,6 +355,7 @@ idist_status run_build(idist_index* ix) {
     a.touched = d_touched;
     a.nbr_dist = d_nbr_dist;
     a.row_nsel = d_row_nsel;
+    a.nbr_aux = d_nbr_aux;
     a.slow = d_slow;
     a.rt = rt;
     a.n_touched = d_small;

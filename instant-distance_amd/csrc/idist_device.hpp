@@ -385,7 +385,10 @@ struct HeurCounters { uint32_t n_dist, n_rows; };
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ int select_heuristic(const IndexView& ix, const uint64_t* Wsrc, int nw, bool keep_pruned,
                                                 float* cq, uint64_t* sel, uint64_t* disc, uint32_t* act_pid,
-                                                uint32_t* act_dist, HeurCounters& hc, int& n_selected) {
+                                                uint32_t* act_dist, HeurCounters& hc, int& n_selected,
+                                                uint32_t* dprn, uint32_t* out_aux) {
+    // dprn[j] (64): pid of a selected member that pruned disc[j]; out_aux[i] (64): 0 for a selected
+    // entry of the result, else the pruner of the back-filled entry (memoised re-selection, build)
     const int lane = lane_id();
     int nsel = 0, ndis = 0;
     for (int wi = 0; wi < nw; wi++) {                      // :668
@@ -393,6 +396,7 @@ __device__ __forceinline__ int select_heuristic(const IndexView& ix, const uint6
         const uint64_t c = Wsrc[wi] & kKeyMask;
         const uint32_t cd = (uint32_t)(c >> 32);
         bool pruned = false;
+        uint32_t pr_pid = 0;
         if (nsel > 0) {
             // stage points[candidate.pid] (:675) once, then 8 results per wave round
             const float* crow = ix.points + (size_t)(uint32_t)c * ix.stride;
@@ -408,22 +412,26 @@ __device__ __forceinline__ int select_heuristic(const IndexView& ix, const uint6
                 wave_sync();
                 hc.n_dist += (uint32_t)cnt;
                 const bool closer = lane < cnt && act_dist[lane] < cd;   // strict <, :678
-                pruned = __ballot(closer) != 0ull;
+                const uint64_t cm = __ballot(closer);
+                pruned = cm != 0ull;
+                if (pruned) pr_pid = (uint32_t)sel[b + __builtin_ctzll(cm)];
                 wave_sync();
             }
         }
         if (lane == 0) {                                   // :681-684
             if (!pruned) sel[nsel] = c;
-            else if (ndis < kM2) disc[ndis] = c;           // only the first 64 discarded can ever be back-filled
+            else if (ndis < kM2) { disc[ndis] = c; dprn[ndis] = pr_pid; }   // only the first 64 discarded can be back-filled
         }
         if (!pruned) nsel++; else ndis++;
         wave_sync();
     }
     n_selected = nsel;
+    out_aux[lane] = 0u;
+    wave_sync();
     if (keep_pruned) {                                     // :687-695
         int take = kM2 - nsel;
         if (take > ndis) take = ndis;
-        if (lane < take) sel[nsel + lane] = disc[lane];
+        if (lane < take) { sel[nsel + lane] = disc[lane]; out_aux[nsel + lane] = dprn[lane]; }
         if (take > 0) nsel += take;
         wave_sync();
     }
@@ -516,7 +524,7 @@ __device__ __forceinline__ void tile_copy(const IndexView& ix, const Tile& t, in
 
 // any R[b..b+cnt) (slots b..) closer to the candidate in slot `cslot` than cd?  (core/lib.rs:676-679)
 template <int NB, int RS, int TAIL>
-__device__ __forceinline__ bool tile_any_closer(const IndexView& ix, const Tile& t, int cslot, int b, int cnt, uint32_t cd) {
+__device__ __forceinline__ uint64_t tile_any_closer(const IndexView& ix, const Tile& t, int cslot, int b, int cnt, uint32_t cd) {
     const int lane = lane_id();
     const int g = lane >> 3, j = lane & 7;
     const int nb = NB >= 0 ? NB : (int)ix.nb;
@@ -564,13 +572,14 @@ __device__ __forceinline__ bool tile_any_closer(const IndexView& ix, const Tile&
     const float s = a4 + __shfl_xor(a4, 2, 64);
     const float r = s + __shfl_xor(s, 1, 64);
     const bool closer = on && j == 0 && canon_bits(r, ix.metric) < cd;   // strict <, core/lib.rs:678
-    return __ballot(closer) != 0ull;
+    return __ballot(closer);   // bit 8*g set <=> R[b+g] is closer
 }
 
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ int select_heuristic_tiled(const IndexView& ix, const uint64_t* Wsrc, int nw, bool keep_pruned,
                                                       const Tile& t, uint64_t* sel, uint64_t* disc, uint32_t* act_pid,
-                                                      uint32_t* act_dist, HeurCounters& hc, int& n_selected) {
+                                                      uint32_t* act_dist, HeurCounters& hc, int& n_selected,
+                                                      uint32_t* dprn, uint32_t* out_aux) {
     const int lane = lane_id();
     const int nb = NB >= 0 ? NB : (int)ix.nb;
     int nsel = 0, ndis = 0;
@@ -586,10 +595,13 @@ __device__ __forceinline__ int select_heuristic_tiled(const IndexView& ix, const
             const uint32_t cd = (uint32_t)(c >> 32);
             const int cslot = t.rt + u;
             bool pruned = false;
+            uint32_t pr_pid = 0;
             const int nl = nsel < t.rt ? nsel : t.rt;                // `any`, :676-679, early exit per 8
             for (int b = 0; b < nl && !pruned; b += 8) {
                 const int c8 = nl - b < 8 ? nl - b : 8;
-                pruned = tile_any_closer<NB, RS, TAIL>(ix, t, cslot, b, c8, cd);
+                const uint64_t cm = tile_any_closer<NB, RS, TAIL>(ix, t, cslot, b, c8, cd);
+                pruned = cm != 0ull;
+                if (pruned) pr_pid = (uint32_t)sel[b + (__builtin_ctzll(cm) >> 3)];
                 hc.n_dist += (uint32_t)c8;
             }
             for (int b = t.rt; b < nsel && !pruned; b += 8) {        // selected rows that did not fit on chip
@@ -600,25 +612,29 @@ __device__ __forceinline__ int select_heuristic_tiled(const IndexView& ix, const
                 dist_rounds<NB, RS, TAIL>(ix, tile_view(t, cslot), act_pid + 8, act_dist, c8);
                 wave_sync();
                 hc.n_dist += (uint32_t)c8;
-                pruned = __ballot(lane < c8 && act_dist[lane] < cd) != 0ull;
+                const uint64_t cm = __ballot(lane < c8 && act_dist[lane] < cd);
+                pruned = cm != 0ull;
+                if (pruned) pr_pid = (uint32_t)sel[b + __builtin_ctzll(cm)];
             }
             if (!pruned) {                                           // :681-684
                 if (lane == 0) sel[nsel] = c;
                 if (nsel < t.rt) tile_copy(ix, t, nb, nsel, cslot);
                 nsel++;
             } else {
-                if (lane == 0 && ndis < kM2) disc[ndis] = c;
+                if (lane == 0 && ndis < kM2) { disc[ndis] = c; dprn[ndis] = pr_pid; }
                 ndis++;
             }
             wave_sync();
         }
     }
     n_selected = nsel;
+    out_aux[lane] = 0u;
+    wave_sync();
     if (keep_pruned) {                                               // :687-695
         if (ndis > kM2) ndis = kM2;
         int take = kM2 - nsel;
         if (take > ndis) take = ndis;
-        if (lane < take) sel[nsel + lane] = disc[lane];
+        if (lane < take) { sel[nsel + lane] = disc[lane]; out_aux[nsel + lane] = dprn[lane]; }
         if (take > 0) nsel += take;
         wave_sync();
     }

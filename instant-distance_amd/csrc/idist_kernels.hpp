@@ -286,6 +286,7 @@ struct BuildArgs {
     uint32_t* touched;          // distinct nodes with a non-empty inbox
     uint32_t* n_touched;
     uint32_t* nbr_dist;         // [n][64] distance bits of every zero-row entry to its owner (build scratch)
+    uint32_t* nbr_aux;          // [n][64] for a back-filled entry: pid of a selected member that pruned it
     uint32_t* row_nsel;         // [n] how many leading entries of a zero row were SELECTED (the rest is back-fill)
     uint32_t* slow;             // nodes whose update needs the full re-selection (step B2)
     uint32_t* n_slow;
@@ -301,6 +302,8 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
     const Smem sm = carve(smem_raw, ix.stride, a.wcap, true);
     uint64_t* sel = sm.aux + 64 + 8;
     uint64_t* disc = sel + 64;
+    uint32_t* dprn = reinterpret_cast<uint32_t*>(sm.aux);   // the "news" area is unused in step A
+    uint32_t* out_aux = dprn + 64;
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
     Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot]};
@@ -343,13 +346,15 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
         int nsel;
         if (a.has_heuristic) {
             nsel = select_heuristic<NB, RS, TAIL>(ix, st.W, nw, a.keep_pruned != 0, sm.cq, sel, disc,
-                                                  sm.act_pid, sm.act_dist, hc, n_selected);  // :470-472
+                                                  sm.act_pid, sm.act_dist, hc, n_selected, dprn, out_aux);  // :470-472
         } else {                                                      // select_simple, :466-469, :758-760
             nsel = nw < kM2 ? nw : kM2;
             if (lane < nsel) sel[lane] = st.W[lane] & kKeyMask;
+            out_aux[lane] = 0u;
             n_selected = nsel;
             wave_sync();
         }
+        a.nbr_aux[(size_t)nw_pid * kM2 + lane] = out_aux[lane];
         if (lane == 0) a.row_nsel[nw_pid] = (uint32_t)n_selected;
         // node.set(i, pid) for every found neighbour (:516); the row was all-INVALID
         ix.zero[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
@@ -479,7 +484,7 @@ constexpr int kMaxNewFast = 8;
 constexpr int kFastX = 80;   // columns of the new-vs-{old selected, new} distance table
 __host__ __device__ inline size_t smem_bytes_update_fast(uint32_t stride) {
     return (size_t)stride * 4 + (size_t)(kUpdW + 72 + 64 + 64 + 64) * 8 +
-           (size_t)(kUpdW + kFastX + kMaxNewFast * kFastX + 64 + kMaxNewFast) * 4;
+           (size_t)(kUpdW + kFastX + kMaxNewFast * kFastX + 64 + kMaxNewFast + 64 + 64) * 4;
 }
 
 template <int NB, int RS, int TAIL>
@@ -495,7 +500,9 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
     uint32_t* X = kindx + kUpdW;                                // kFastX pids: old selected, then new
     uint32_t* Dn = X + kFastX;                                  // [kMaxNewFast][kFastX] distance bits
     uint32_t* Rx = Dn + kMaxNewFast * kFastX;                   // x of every member of R
-    uint32_t* addx = Rx + 64;                                   // new points that entered R
+    uint32_t* addx = Rx + 64;                                   // active points that entered R
+    uint32_t* dprn = addx + kMaxNewFast;                        // pruner of disc[j]
+    uint32_t* curaux = dprn + 64;                               // stored pruners of the current row
     enum : uint32_t { OLD_SEL = 0, OLD_DISC = 1, NEW = 2 };
     const int lane = lane_id();
     const uint32_t ntouched = *a.n_touched;
@@ -524,6 +531,7 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
         const uint32_t cur = ix.zero[(size_t)pid * kM2 + lane];
         const uint32_t curd = a.nbr_dist[(size_t)pid * kM2 + lane];
         const int ns0 = (int)a.row_nsel[pid];
+        curaux[lane] = a.nbr_aux[(size_t)pid * kM2 + lane];
         const uint64_t inval = __ballot(cur == kInvalid);
         const int ncur = inval ? __builtin_ctzll(inval) : 64;
         const uint64_t key = lane < ncur ? (((uint64_t)curd << 32) | cur) : kMaxKey;
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
                 rb += o < keyb ? 1 : 0;
             }
             for (int i = 0; i < k_new; i++) ra += (news[i] & kKeyMask) < key ? 1 : 0;
-            if (lane < ncur) { W[ra] = key; kindx[ra] = lane < ns0 ? ((OLD_SEL << 8) | (uint32_t)lane) : (OLD_DISC << 8); }
+            if (lane < ncur) { W[ra] = key; kindx[ra] = ((lane < ns0 ? OLD_SEL : OLD_DISC) << 8) | (uint32_t)lane; }
             if (lane < k_new) { W[rb] = keyb; kindx[rb] = (NEW << 8) | (uint32_t)(ns0 + lane); }
             wave_sync();
             // distances of every new point to {old selected} U {new}  (Point::distance is symmetric bit for bit)
@@ -560,8 +568,7 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
                 hc.n_rows += 1;
             }
             // replay of select_heuristic (core/lib.rs:668-685) on stored verdicts
-            int nAdd = 0;
-            bool removed = false;
+            int nAdd = 0, nAct = k_new;
             for (int i = 0; i < total; i++) {
                 if (nR >= kM2) break;                                   // :669-671
                 const uint64_t c = W[i];
@@ -569,30 +576,67 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
                 const uint32_t kind = kx >> 8, x = kx & 255u;
                 const uint32_t cd = (uint32_t)(c >> 32);
                 bool pruned;
+                uint32_t pr_pid = 0, cx = x;
                 if (kind == OLD_SEL) {
+                    // passed every older selected member already: only members added since can prune it
                     bool closer = false;
                     if (lane < nAdd) closer = Dn[addx[lane] * kFastX + x] < cd;          // strict <, :678
-                    pruned = __ballot(closer) != 0ull;
-                    if (pruned) removed = true;
+                    const uint64_t cm = __ballot(closer);
+                    pruned = cm != 0ull;
+                    if (pruned) pr_pid = X[ns0 + addx[__builtin_ctzll(cm)]];
                 } else if (kind == OLD_DISC) {
-                    if (removed) { defer = true; break; }               // its pruner may be gone: full re-selection
-                    pruned = true;
+                    // stays discarded while the member that pruned it is still selected
+                    const uint32_t p = curaux[x];
+                    const bool still = __ballot(lane < nR && (uint32_t)sel[lane] == p) != 0ull;
+                    if (still) {
+                        pruned = true;
+                        pr_pid = p;
+                    } else {
+                        // its pruner is gone: evaluate it like a new point against the current selected set
+                        if (nAct >= kMaxNewFast) { defer = true; break; }
+                        const int ci = nAct++;
+                        if (lane == 0) X[ns0 + ci] = (uint32_t)c;
+                        const float* prow = ix.points + (size_t)(uint32_t)c * ix.stride;
+                        for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+                            *reinterpret_cast<float4*>(cq + o) = *reinterpret_cast<const float4*>(prow + o);
+                        wave_sync();
+                        dist_rounds<NB, RS, TAIL>(ix, cq, X, Dn + ci * kFastX, ns0 + ci);
+                        wave_sync();
+                        hc.n_dist += (uint32_t)(ns0 + ci);
+                        hc.n_rows += 1;
+                        bool closer = false;
+                        if (lane < nR) closer = Dn[ci * kFastX + Rx[lane]] < cd;          // columns of all earlier actives exist
+                        const uint64_t cm = __ballot(closer);
+                        pruned = cm != 0ull;
+                        if (pruned) pr_pid = (uint32_t)sel[__builtin_ctzll(cm)];
+                        cx = (uint32_t)(ns0 + ci);
+                    }
                 } else {
+                    const uint32_t ai = x - (uint32_t)ns0;
                     bool closer = false;
-                    if (lane < nR) closer = Dn[(x - (uint32_t)ns0) * kFastX + Rx[lane]] < cd;
-                    pruned = __ballot(closer) != 0ull;
+                    if (lane < nR) {
+                        const uint32_t xr = Rx[lane];
+                        // distance between two active points: the row of the later-activated one has the column
+                        const uint32_t dv = (xr < (uint32_t)ns0 || xr - (uint32_t)ns0 < ai) ? Dn[ai * kFastX + xr]
+                                                                                          : Dn[(xr - (uint32_t)ns0) * kFastX + x];
+                        closer = dv < cd;
+                    }
+                    const uint64_t cm = __ballot(closer);
+                    pruned = cm != 0ull;
+                    if (pruned) pr_pid = (uint32_t)sel[__builtin_ctzll(cm)];
                 }
                 wave_sync();
                 if (lane == 0) {
                     if (!pruned) {
                         sel[nR] = c;
-                        Rx[nR] = x;
-                        if (kind == NEW) addx[nAdd] = x - (uint32_t)ns0;
+                        Rx[nR] = cx;
+                        if (cx >= (uint32_t)ns0) addx[nAdd] = cx - (uint32_t)ns0;
                     } else if (nD < kM2) {
                         disc[nD] = c;
+                        dprn[nD] = pr_pid;
                     }
                 }
-                if (!pruned) { nR++; if (kind == NEW) nAdd++; } else { nD++; }
+                if (!pruned) { nR++; if (cx >= (uint32_t)ns0) nAdd++; } else { nD++; }
                 wave_sync();
             }
         }
@@ -615,6 +659,7 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
         }
         ix.zero[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;     // ZeroNode::rewrite
         a.nbr_dist[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)(sel[lane] >> 32) : 0u;
+        a.nbr_aux[(size_t)pid * kM2 + lane] = (lane >= nR && lane < nsel) ? dprn[lane - nR] : 0u;
         updates++;
         wave_sync();
     }
@@ -642,7 +687,7 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
 // the selected set stays in that tile, so every row crosses HBM once per update.
 // ---------------------------------------------------------------------------
 __host__ __device__ inline size_t smem_bytes_update(uint32_t nb, uint32_t rt) {
-    return tile_floats(nb, rt + 8) * 4 + (size_t)(kUpdW + 72 + 64 + 64 + 64) * 8 + 2 * 64 * 4;
+    return tile_floats(nb, rt + 8) * 4 + (size_t)(kUpdW + 72 + 64 + 64 + 64) * 8 + 4 * 64 * 4;
 }
 
 template <int NB, int RS, int TAIL>
@@ -662,6 +707,8 @@ __global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArg
     uint64_t* curk = disc + 64;
     uint32_t* act_pid = reinterpret_cast<uint32_t*>(curk + 64);
     uint32_t* act_dist = act_pid + 64;
+    uint32_t* dprn = act_dist + 64;
+    uint32_t* out_aux = dprn + 64;
     const int lane = lane_id();
     const uint32_t nslow = *a.n_slow;
     HeurCounters hc{0, 0};
@@ -728,8 +775,9 @@ __global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArg
         // select_heuristic over ALL of `nearest` (no truncate in add_neighbor_heuristic, :630)
         int n_selected = 0;
         const int nsel = select_heuristic_tiled<NB, RS, TAIL>(ix, st.W, st.plen, a.keep_pruned != 0, tile, sel, disc,
-                                                              act_pid, act_dist, hc, n_selected);
+                                                              act_pid, act_dist, hc, n_selected, dprn, out_aux);
         if (lane == 0) a.row_nsel[pid] = (uint32_t)n_selected;
+        a.nbr_aux[(size_t)pid * kM2 + lane] = out_aux[lane];
         // ZeroNode::rewrite (core/types.rs:88-98): rows are prefix-valid, so clearing to the end is identical
         ix.zero[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
         a.nbr_dist[(size_t)pid * kM2 + lane] = lane < nsel ? (uint32_t)(sel[lane] >> 32) : 0u;
