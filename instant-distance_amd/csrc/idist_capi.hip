@@ -3,6 +3,7 @@
 // of the build (Hnsw::new, core/lib.rs:209-345) and of the batched search.
 #include "../../include/idist.h"
 #include "idist_kernels.hpp"
+#include "idist_mfma.hpp"
 
 #ifndef IDIST_EMU
 #include <hip/hip_runtime.h>
@@ -871,8 +872,8 @@ idist_status idist_distance_batch(const idist_index* idx, const float* queries, 
     return IDIST_OK;
 }
 
-idist_status idist_bruteforce(const idist_index* idx, const float* queries, uint32_t nq, uint32_t k,
-                              uint32_t* out_pid, float* out_dist) {
+static idist_status bruteforce_scan(const idist_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                                    uint32_t* out_pid, float* out_dist) {
     if (!idx) return fail(IDIST_ERR_INVALID_ARG, "idx is null");
     if (nq == 0) return IDIST_OK;
     if (k == 0 || k > IDIST_MAX_EF) return fail(IDIST_ERR_INVALID_ARG, "k %u out of [1,%u]", k, IDIST_MAX_EF);
@@ -908,6 +909,121 @@ idist_status idist_bruteforce(const idist_index* idx, const float* queries, uint
     }
     release();
     return IDIST_OK;
+}
+
+
+// Wide-batch exact k-NN: f32-MFMA -2QP^T filter + canonical re-rank (idist_mfma.hpp).  Returns
+// IDIST_ERR_INTERNAL with *fell_back = 1 if a candidate list overflowed (caller rescans).
+static idist_status bruteforce_mfma(const idist_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                                    uint32_t* out_pid, float* out_dist, int* fell_back) {
+    *fell_back = 0;
+    const uint32_t n = idx->n, stride = idx->L.stride;
+    uint32_t S = 32768;
+    if (const char* e = getenv("IDIST_BF_SAMPLE")) S = (uint32_t)atoi(e);
+    S = std::min(std::max(S, k), n);
+    const uint32_t S_pad = (S + kTN - 1) / kTN * kTN;
+    const uint32_t QC = 8192;                                    // queries per pass (bounds the dense sample matrix)
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)8 * k * n / S + 256, 1024), 1u << 16);
+    float *d_qnat = nullptr, *d_qb = nullptr, *d_qn = nullptr, *d_pn = nullptr, *d_dense = nullptr, *d_thr = nullptr, *d_dist = nullptr;
+    uint32_t *d_cand = nullptr, *d_cnt = nullptr, *d_pid = nullptr, *d_ovf = nullptr;
+    auto release = [&]() {
+        hipFree(d_qnat); hipFree(d_qb); hipFree(d_qn); hipFree(d_pn); hipFree(d_dense); hipFree(d_thr); hipFree(d_dist);
+        hipFree(d_cand); hipFree(d_cnt); hipFree(d_pid); hipFree(d_ovf);
+    };
+#define MCHK(expr)                                                                                  \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            release();                                                                              \
+            return fail(IDIST_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                           \
+    } while (0)
+    const uint32_t qc_max = std::min(nq, QC);
+    const uint32_t qc_pad = (qc_max + kTM - 1) / kTM * kTM;
+    MCHK(hipMalloc((void**)&d_qnat, (size_t)qc_max * idx->dim * 4));
+    MCHK(hipMalloc((void**)&d_qb, (size_t)qc_pad * stride * 4));
+    MCHK(hipMalloc((void**)&d_qn, (size_t)qc_pad * 4));
+    MCHK(hipMalloc((void**)&d_pn, (size_t)n * 4));
+    MCHK(hipMalloc((void**)&d_dense, (size_t)qc_pad * S_pad * 4));
+    MCHK(hipMalloc((void**)&d_thr, (size_t)qc_pad * 4));
+    MCHK(hipMalloc((void**)&d_cand, (size_t)qc_max * cap * 4));
+    MCHK(hipMalloc((void**)&d_cnt, (size_t)qc_pad * 4));
+    MCHK(hipMalloc((void**)&d_pid, (size_t)qc_max * k * 4));
+    MCHK(hipMalloc((void**)&d_dist, (size_t)qc_max * k * 4));
+    MCHK(hipMalloc((void**)&d_ovf, 256));
+    MCHK(hipMemset(d_ovf, 0, 256));
+    hipStream_t st = nullptr;
+    const uint32_t ngrid = std::min<uint32_t>(n, (uint32_t)idx->n_cu * 32);
+    IDIST_LAUNCH(row_norms_kernel, ngrid, 64, 0, st, idx->d_points, n, stride, d_pn);
+    std::vector<float> pn_h(n);
+    MCHK(hipMemcpy(pn_h.data(), d_pn, (size_t)n * 4, hipMemcpyDeviceToHost));
+    const float pn_max = *std::max_element(pn_h.begin(), pn_h.end());
+    IndexView view = idx->view();
+    const size_t smem_g = (size_t)2 * kTM * kLDP * 4;
+    for (uint32_t qb = 0; qb < nq; qb += QC) {
+        const uint32_t qc = std::min(QC, nq - qb);
+        const uint32_t qpad = (qc + kTM - 1) / kTM * kTM;
+        MCHK(hipMemcpy(d_qnat, queries + (size_t)qb * idx->dim, (size_t)qc * idx->dim * 4, hipMemcpyHostToDevice));
+        MCHK(hipMemset(d_qb, 0, (size_t)qpad * stride * 4));
+        {
+            const size_t total = (size_t)qc * stride;
+            const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
+            IDIST_LAUNCH(permute_rows_kernel, grid, 256, 0, st, d_qnat, d_qb, qc, idx->dim, stride, idx->L.nb);
+        }
+        IDIST_LAUNCH(row_norms_kernel, std::min<uint32_t>(qpad, 8192), 64, 0, st, d_qb, qpad, stride, d_qn);
+        MfmaArgs a{};
+        a.Q = d_qb; a.P = idx->d_points; a.qn = d_qn; a.pn = d_pn;
+        a.nq = qc; a.n = n; a.stride = stride;
+        a.dense = d_dense; a.dense_ld = S_pad; a.thr = d_thr; a.cand = d_cand; a.cnt = d_cnt; a.cap = cap;
+        const uint32_t nqt = qpad / kTM;
+        // pass 1: dense distances to the sample [0, S) -> per-query threshold
+        a.mode = 0; a.p_begin = 0; a.p_end = S;
+        IDIST_LAUNCH(mfma_dist_kernel, nqt * (S_pad / kTN), 256, smem_g, st, a);
+        IDIST_LAUNCH(kth_threshold_kernel, std::min<uint32_t>(qc, 8192), 64, (size_t)(k + 72) * 8, st, d_dense, S_pad, S, qc, k,
+                     k + 72, d_qn, pn_max, d_thr);
+        // pass 2: all points, keep those under the threshold
+        MCHK(hipMemsetAsync(d_cnt, 0, (size_t)qpad * 4, st));
+        a.mode = 1; a.p_begin = 0; a.p_end = n;
+        IDIST_LAUNCH(mfma_dist_kernel, nqt * ((n + kTN - 1) / kTN), 256, smem_g, st, a);
+        // pass 3: canonical re-rank of the candidates
+        const uint32_t wcap = k + 64 + 8;
+        const size_t smem_r = (size_t)stride * 4 + (size_t)wcap * 8 + 2 * 64 * 4;
+        const uint32_t gridr = std::min<uint32_t>(qc, (uint32_t)idx->n_cu * 16);
+#define LAUNCH_RR(NB_, RS_, TAIL_)                                                                                   \
+    {                                                                                                                \
+        auto kR = rerank_kernel<NB_, RS_, TAIL_>;                                                                    \
+        IDIST_LAUNCH(kR, gridr, 64, smem_r, st, view, d_qnat, qc, k, wcap, d_cand, d_cnt, cap, d_pid, d_dist, d_ovf); \
+    }
+        IDIST_DISPATCH(idx->L, LAUNCH_RR);
+#undef LAUNCH_RR
+        MCHK(hipGetLastError());
+        MCHK(hipMemcpy(out_pid + (size_t)qb * k, d_pid, (size_t)qc * k * 4, hipMemcpyDeviceToHost));
+        MCHK(hipMemcpy(out_dist + (size_t)qb * k, d_dist, (size_t)qc * k * 4, hipMemcpyDeviceToHost));
+    }
+    uint32_t ovf = 0;
+    MCHK(hipMemcpy(&ovf, d_ovf, 4, hipMemcpyDeviceToHost));
+#undef MCHK
+    release();
+    if (ovf) { *fell_back = 1; return fail(IDIST_ERR_INTERNAL, "MFMA filter: %u candidate lists overflowed", ovf); }
+    return IDIST_OK;
+}
+
+idist_status idist_bruteforce(const idist_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                              uint32_t* out_pid, float* out_dist) {
+    if (!idx) return fail(IDIST_ERR_INVALID_ARG, "idx is null");
+    if (nq == 0) return IDIST_OK;
+    if (k == 0 || k > IDIST_MAX_EF) return fail(IDIST_ERR_INVALID_ARG, "k %u out of [1,%u]", k, IDIST_MAX_EF);
+    if (!queries || !out_pid || !out_dist) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
+    // the -2QP^T contraction only pays when the batch is wide enough to be a dense GEMM
+    bool mfma = nq >= 256 && idx->n >= 16384;
+    if (const char* e = getenv("IDIST_BRUTEFORCE")) mfma = strcmp(e, "mfma") == 0 ? true : (strcmp(e, "scan") == 0 ? false : mfma);
+    if (mfma && idx->n >= k && idx->n >= 128) {
+        HIPCHK(hipSetDevice(idx->device));
+        int fell_back = 0;
+        idist_status s = bruteforce_mfma(idx, queries, nq, k, out_pid, out_dist, &fell_back);
+        if (s == IDIST_OK || !fell_back) return s;
+    }
+    return bruteforce_scan(idx, queries, nq, k, out_pid, out_dist);
 }
 
 }  // extern "C"

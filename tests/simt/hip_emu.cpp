@@ -1,6 +1,8 @@
 // hip_emu.cpp — scheduler of the CPU lockstep emulator (TEST INFRASTRUCTURE, see hip_emu.hpp).
 #include "hip_emu.hpp"
 
+#include <algorithm>
+
 namespace emu {
 
 State& S() {
@@ -94,48 +96,73 @@ void launch(uint32_t grid, uint32_t block, size_t smem_bytes, const std::functio
                     idist_emu_switch(&s.sched_sp, l.sp);
                 }
             }
-            // every live lane now waits at a collective
-            int op = OP_NONE;
-            uint32_t n_alive = 0, first = block;
-            for (uint32_t i = 0; i < block; i++) {
-                Lane& l = s.lanes[i];
-                if (!l.alive) continue;
-                if (first == block) first = i;
-                n_alive++;
-                if (op == OP_NONE) op = l.op;
-                else if (op != l.op) {
-                    fprintf(stderr, "[hip_emu] DIVERGENT COLLECTIVE in block %u: lane %u at %s, lane %u at %s\n", b, first,
-                            op_name(op), i, op_name(l.op));
+            // every live lane now waits at a collective: wave collectives resolve per wave (64 lanes),
+            // __syncthreads when the whole workgroup has arrived
+            uint32_t n_alive = 0;
+            for (uint32_t i = 0; i < block; i++) n_alive += s.lanes[i].alive ? 1u : 0u;
+            if (!n_alive) break;
+            bool progressed = false;
+            const uint32_t n_waves = (block + 63) / 64;
+            bool all_sync = true;
+            for (uint32_t w = 0; w < n_waves; w++) {
+                const uint32_t lo = w * 64, hi = std::min(block, lo + 64);
+                int op = OP_NONE;
+                uint32_t first = hi, alive = 0;
+                for (uint32_t i = lo; i < hi; i++) {
+                    Lane& l = s.lanes[i];
+                    if (!l.alive) continue;
+                    if (first == hi) first = i;
+                    alive++;
+                    if (op == OP_NONE) op = l.op;
+                    else if (op != l.op) {
+                        fprintf(stderr, "[hip_emu] DIVERGENT COLLECTIVE in block %u wave %u: lane %u at %s, lane %u at %s\n", b, w,
+                                first, op_name(op), i, op_name(l.op));
+                        abort();
+                    }
+                }
+                if (!alive) continue;
+                if (op == OP_SYNC) continue;
+                all_sync = false;
+                if (alive != hi - lo && getenv("IDIST_EMU_STRICT")) {
+                    fprintf(stderr, "[hip_emu] collective %s with %u/%u lanes alive\n", op_name(op), alive, hi - lo);
                     abort();
                 }
-            }
-            if (!n_alive) break;
-            if (n_alive != block && op != OP_SYNC && getenv("IDIST_EMU_STRICT")) {
-                fprintf(stderr, "[hip_emu] collective %s with %u/%u lanes alive\n", op_name(op), n_alive, block);
-                abort();
-            }
-            if (op != OP_SYNC && block > 64) {
-                fprintf(stderr, "[hip_emu] wave collective in a %u-thread block is not modelled\n", block);
-                abort();
-            }
-            s.n_collectives++;
-            uint64_t ballot = 0;
-            if (op == OP_BALLOT)
-                for (uint32_t i = 0; i < block; i++)
-                    if (s.lanes[i].alive && s.lanes[i].val) ballot |= 1ull << i;
-            for (uint32_t i = 0; i < block; i++) {
-                Lane& l = s.lanes[i];
-                if (!l.alive) continue;
-                switch (op) {
-                    case OP_SYNC: l.res = 0; break;
-                    case OP_BALLOT: l.res = ballot; break;
-                    case OP_SHFL: { const Lane& o = s.lanes[(uint32_t)l.arg % block]; l.res = o.alive ? o.val : 0; break; }
-                    case OP_SHFL_XOR: { const uint32_t j = i ^ (uint32_t)l.arg; l.res = (j < block && s.lanes[j].alive) ? s.lanes[j].val : l.val; break; }
-                    case OP_READFIRST: l.res = s.lanes[first].val; break;
-                    default: break;
+                s.n_collectives++;
+                uint64_t ballot = 0;
+                if (op == OP_BALLOT)
+                    for (uint32_t i = lo; i < hi; i++)
+                        if (s.lanes[i].alive && s.lanes[i].val) ballot |= 1ull << (i - lo);
+                for (uint32_t i = lo; i < hi; i++) {
+                    Lane& l = s.lanes[i];
+                    if (!l.alive) continue;
+                    const uint32_t li = i - lo;
+                    switch (op) {
+                        case OP_BALLOT: l.res = ballot; break;
+                        case OP_SHFL: { const Lane& o = s.lanes[lo + ((uint32_t)l.arg & 63u)]; l.res = (lo + ((uint32_t)l.arg & 63u) < hi && o.alive) ? o.val : 0; break; }
+                        case OP_SHFL_XOR: { const uint32_t j = lo + (li ^ (uint32_t)l.arg); l.res = (j < hi && s.lanes[j].alive) ? s.lanes[j].val : l.val; break; }
+                        case OP_READFIRST: l.res = s.lanes[first].val; break;
+                        case OP_MFMA_32x32x2: {
+                            const uint32_t col = li & 31u;
+                            for (int r = 0; r < 16; r++) {
+                                const uint32_t row = (uint32_t)(r & 3) + 8u * (uint32_t)(r >> 2) + 4u * (li >> 5);
+                                float acc = l.c[r];
+                                for (uint32_t k = 0; k < 2; k++)
+                                    acc = fmaf(s.lanes[lo + k * 32 + row].a, s.lanes[lo + k * 32 + col].b, acc);
+                                l.d[r] = acc;
+                            }
+                            break;
+                        }
+                        default: break;
+                    }
+                    l.waiting = false;
                 }
+                progressed = true;
             }
-            for (uint32_t i = 0; i < block; i++) s.lanes[i].waiting = false;
+            if (!progressed) {
+                if (!all_sync) { fprintf(stderr, "[hip_emu] deadlock in block %u\n", b); abort(); }
+                s.n_collectives++;
+                for (uint32_t i = 0; i < block; i++) { s.lanes[i].res = 0; s.lanes[i].waiting = false; }
+            }
         }
     }
     free(sm);

@@ -36,7 +36,7 @@ namespace emu {
 
 struct Dim3 { uint32_t x, y, z; };
 
-enum Op { OP_NONE = 0, OP_SYNC, OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_READFIRST };
+enum Op { OP_NONE = 0, OP_SYNC, OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_READFIRST, OP_MFMA_32x32x2 };
 
 struct Lane {
     void* sp = nullptr;          // saved stack pointer
@@ -46,6 +46,7 @@ struct Lane {
     int op = OP_NONE;
     uint64_t val = 0, res = 0;
     int arg = 0;
+    float a = 0, b = 0, c[16] = {0}, d[16] = {0};   // MFMA operands / result
 };
 
 extern "C" void idist_emu_switch(void** save_sp, void* new_sp);
@@ -108,6 +109,24 @@ static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) {
     return (uint32_t)::emu::collective(::emu::OP_READFIRST, v, 0);
 }
 static inline void __threadfence_block() {}
+
+// v_mfma_f32_32x32x2_f32: D = A(32x2) * B(2x32) + C, exact f32, k-ordered fma chain.
+// lane l: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]; C/D reg r: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+struct f32x16 {
+    float v[16];
+    float& operator[](int i) { return v[i]; }
+    const float& operator[](int i) const { return v[i]; }
+};
+static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) {
+    ::emu::Lane* l = ::emu::S().cur;
+    l->a = a;
+    l->b = b;
+    for (int i = 0; i < 16; i++) l->c[i] = c[i];
+    ::emu::collective(::emu::OP_MFMA_32x32x2, 0, 0);
+    f32x16 d;
+    for (int i = 0; i < 16; i++) d[i] = l->d[i];
+    return d;
+}
 
 // ---- scalar helpers ----
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

@@ -179,6 +179,33 @@ def test_bruteforce(eng, oracle):
     assert np.array_equal(pid, opid) and np.array_equal(pc.bits(dist), pc.bits(odist))
 
 
+def test_bruteforce_mfma_path_equals_scan(eng, oracle, monkeypatch):
+    """BASELINE config C4's distance path: the f32-MFMA -2QP^T filter + canonical re-rank must return
+    exactly what the scan kernel (and the oracle) return."""
+    ida, kind = eng
+    rng = np.random.default_rng(11)
+    n, dim, nq, k = S(kind, 300, 60000), S(kind, 20, 300), S(kind, 130, 700), S(kind, 10, 10)
+    pts = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q[:3] = pts[[5, 17, n - 1]]
+    h = ida.Hnsw.from_parts(pts, np.full((n, 64), pc.INVALID, np.uint32), [], ida.Builder())
+    monkeypatch.setenv("IDIST_BRUTEFORCE", "scan")
+    p1, d1 = h.bruteforce(q, k)
+    monkeypatch.setenv("IDIST_BRUTEFORCE", "mfma")
+    monkeypatch.setenv("IDIST_BF_SAMPLE", str(S(kind, 64, 8192)))
+    p2, d2 = h.bruteforce(q, k)
+    assert np.array_equal(p1, p2) and np.array_equal(pc.bits(d1), pc.bits(d2))
+    sub = slice(0, S(kind, nq, 40))
+    op, od = oracle.bruteforce(pts, q[sub], k, threads=4)
+    assert np.array_equal(p1[sub], op) and np.array_equal(pc.bits(d1[sub]), pc.bits(od))
+    # tiny sample + large k: candidate lists overflow -> the call must still be exact (falls back to the scan)
+    monkeypatch.setenv("IDIST_BF_SAMPLE", "1")
+    p3, _ = h.bruteforce(q[:S(kind, 130, 300)], S(kind, 40, 100))
+    monkeypatch.setenv("IDIST_BRUTEFORCE", "scan")
+    p4, _ = h.bruteforce(q[:S(kind, 130, 300)], S(kind, 40, 100))
+    assert np.array_equal(p3, p4)
+
+
 def test_edge_cases(eng, oracle):
     ida, kind = eng
     s = ida.Search()
