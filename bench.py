@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--ef", type=int, default=0, help="ef_search; 0 = smallest of 100/200/400/800 reaching the recall target")
     ap.add_argument("--recall-target", type=float, default=0.95)
-    ap.add_argument("--gt-queries", type=int, default=1000, help="queries with exact ground truth (recall estimate)")
+    ap.add_argument("--gt-queries", type=int, default=0, help="queries with exact ground truth (0 = all; MFMA -2QP^T filter + exact re-rank)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries for the CPU baseline (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-batch", type=int, default=0)
@@ -148,7 +148,7 @@ def main():
                                  ctr.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
     # ---- ground truth (exact scan with the same canonical distance) + ef choice ----
-    gtq = min(args.gt_queries, nq)
+    gtq = min(args.gt_queries or nq, nq)
     truth, _ = hnsw.bruteforce(d_q[:gtq].cpu().numpy(), k)
     sweep = {}
     ef_list = [args.ef] if args.ef else [100, 200, 400, 800]

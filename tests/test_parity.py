@@ -167,6 +167,74 @@ def test_build_batched_matches_oracle_recall_gpu(engine_loader, oracle):
     assert abs(dz - do) < 4, (dz, do)
 
 
+@pytest.mark.gpu
+def test_c3_full_size_properties_gpu(engine_loader, oracle):
+    """BASELINE config C3 at full size (1M x 300 f32): build on the GPU, then (i) size-independent
+    properties, (ii) the oracle searching the SAME exported graph must agree bit for bit, (iii) exact
+    recall against the MFMA-filtered brute force."""
+    ida = engine_loader("gpu")
+    rng = np.random.default_rng(3)
+    n, dim = 1_000_000, 300
+    z = rng.standard_normal((n, 32), dtype=np.float32)
+    a = np.random.default_rng(4242).standard_normal((32, dim), dtype=np.float32)
+    pts = z @ a
+    pts += 0.05 * rng.standard_normal((n, dim), dtype=np.float32)
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    q = pts[rng.integers(0, n, 64)] + 0.02 * rng.standard_normal((64, dim), dtype=np.float32)
+    q = np.concatenate([pts[:64], q.astype(np.float32)])
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder())
+    st = h.build_stats()
+    assert st.n_updates_fast + st.n_updates_full == st.n_updates
+    got = h.search_batch(q, ida.Search(), counters=True)
+    assert np.all(got.count == 100) and np.all(got.distance[:, :-1] <= got.distance[:, 1:])
+    assert np.array_equal(got.pid[:64, 0], np.arange(64)) and np.all(got.distance[:64, 0] == 0)   # self query
+    zero, layers = h.into_parts()
+    assert [l.shape[0] for l in layers] == oracle.layer_sizes(n)[1:]
+    valid = zero != pc.INVALID
+    assert np.all(valid[:, :-1] >= valid[:, 1:]) and np.all(zero[valid] < n) and valid.sum(1).min() >= 1
+    oix = oracle.Index.from_arrays(pts, zero, layers, oracle.default_config())
+    want = oix.search(q, threads=8)
+    assert np.array_equal(got.pid, want.pid) and np.array_equal(got.counters, want.counters)
+    assert np.array_equal(pc.bits(got.distance), pc.bits(want.dist))
+    truth, _ = h.bruteforce(np.repeat(q, 2, axis=0), 10)        # 256 queries -> MFMA path
+    assert pc.recall_at(got.pid, truth[::2], 10) > 0.9
+
+
+@pytest.mark.gpu
+def test_device_views_alias_index_gpu(engine_loader, oracle):
+    """The zero-copy views used for RCCL replication alias the index's device buffers."""
+    import torch
+
+    ida = engine_loader("gpu")
+    from instant_distance_amd import dist as idd
+
+    rng = np.random.default_rng(0)
+    pts = rng.random((3000, 300), dtype=np.float32)
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder())
+    v_pts, v_zero, v_upper = idd.device_views(h, torch.device("cuda", 0))
+    zero, layers = h.into_parts()
+    assert np.array_equal(v_zero.cpu().numpy().view(np.uint32).reshape(-1, 64), zero)
+    assert np.array_equal(v_upper.cpu().numpy().view(np.uint32).reshape(-1, 32), np.concatenate(layers))
+    stride = h.info().row_stride
+    rows = v_pts.cpu().numpy().view(np.float32).reshape(-1, stride)
+    assert rows.shape[0] == 3000 and np.isclose(np.sort(rows[7])[-300:].sum(), np.sort(pts[7]).sum(), rtol=1e-5)
+    # a replica filled through the views answers identically
+    info = h.info()
+    import ctypes as C
+    from instant_distance_amd import _capi
+    hh = C.c_void_p()
+    cfg = ida.Builder()._config()
+    ll = np.array(list(info.layer_len)[: info.n_upper], dtype=np.uint32)
+    _capi.lib().check(_capi.lib().idist_index_alloc(3000, 300, C.byref(cfg), _capi.u32p(ll), info.n_upper, 0, C.byref(hh)))
+    rep = ida.Hnsw(hh, pts, 100)
+    for dst, src in zip(idd.device_views(rep, torch.device("cuda", 0)), (v_pts, v_zero, v_upper)):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    q = rng.random((50, 300), dtype=np.float32)
+    a, b = h.search_batch(q, ida.Search()), rep.search_batch(q, ida.Search())
+    assert np.array_equal(a.pid, b.pid) and np.array_equal(pc.bits(a.distance), pc.bits(b.distance))
+
+
 def test_bruteforce(eng, oracle):
     ida, kind = eng
     rng = np.random.default_rng(1)
