@@ -66,6 +66,18 @@ __host__ __device__ inline uint32_t blocked_pos(uint32_t e, uint32_t nb) {
     return e;
 }
 
+// 16-byte load of point-row data.  Rows are streamed once per use and never re-read by the same CU, so
+// the build can mark them non-temporal (IDIST_NT=1) to keep adjacency rows / visited bytes in L2.
+#if defined(IDIST_NT) && !defined(IDIST_EMU)
+typedef float idist_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg_row4(const float* p) {
+    const idist_v4f v = __builtin_nontemporal_load(reinterpret_cast<const idist_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#else
+__device__ __forceinline__ float4 ldg_row4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#endif
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }  // single-wave workgroup
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
@@ -121,7 +133,7 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const VecView q
                     float4 p[CH];
 #pragma unroll
                     for (int u = 0; u < CH; u++)
-                        if (t0 + u < NB) p[u] = *reinterpret_cast<const float4*>(row + (t0 + u) * 32 + j * 4);
+                        if (t0 + u < NB) p[u] = ldg_row4(row + (t0 + u) * 32 + j * 4);
 #pragma unroll
                     for (int u = 0; u < CH; u++) {
                         if (t0 + u < NB) {
@@ -136,7 +148,7 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const VecView q
                 }
             } else {
                 for (int t = 0; t < nb; t++) {
-                    const float4 p = *reinterpret_cast<const float4*>(row + t * 32 + j * 4);
+                    const float4 p = ldg_row4(row + t * 32 + j * 4);
                     const float4 w = *reinterpret_cast<const float4*>(qv.blk + t * qv.bstride + j * 4);
                     float d;
                     d = w.x - p.x; acc = __builtin_fmaf(d, d, acc);

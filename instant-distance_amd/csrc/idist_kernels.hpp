@@ -24,11 +24,6 @@ __global__ void permute_rows_kernel(const float* __restrict__ in, float* __restr
     }
 }
 
-__global__ void fill_u32_kernel(uint32_t* p, size_t n, uint32_t v) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        p[i] = v;
-}
-
 // UpperNode::from_zero for a whole layer, core/lib.rs:323-328, core/types.rs:66-70
 __global__ void snapshot_kernel(const uint32_t* __restrict__ zero, uint32_t* __restrict__ upper_rows, uint32_t rows) {
     const size_t total = (size_t)rows * kM;
