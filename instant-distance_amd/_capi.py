@@ -113,6 +113,17 @@ class Lib:
                 f"{path} is missing: build it with `make -C instant-distance_amd/csrc` "
                 "(hipcc --offload-arch=gfx950). instant_distance_amd has no CPU fallback.")
         self.path = path
+        # One HIP runtime per process: if torch is already imported, let it bring up ITS runtime first —
+        # torch's bundled libamdhip64 refuses to initialise ("No HIP GPUs are available") once another copy
+        # has opened the device, while libidist happily shares torch's (same SONAME).
+        import sys as _sys
+        _torch = _sys.modules.get("torch")
+        if _torch is not None:
+            try:
+                if _torch.cuda.is_available():
+                    _torch.cuda.init()
+            except Exception:  # noqa: BLE001
+                pass
         self.cdll = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.cdll, name)   # AttributeError if the symbol is not exported

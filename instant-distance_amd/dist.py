@@ -9,6 +9,8 @@ one GPU and is replicated.
 """
 from __future__ import annotations
 
+# NOTE: import torch (and touch torch.cuda) BEFORE the first instant_distance_amd call of the process when
+# you intend to use the device views: both libraries must share one HIP runtime (see _capi.Lib).
 import ctypes as C
 
 import numpy as np

@@ -203,8 +203,19 @@ def test_c3_full_size_properties_gpu(engine_loader, oracle):
 @pytest.mark.gpu
 def test_device_views_alias_index_gpu(engine_loader, oracle):
     """The zero-copy views used for RCCL replication alias the index's device buffers."""
+    import subprocess
+    import sys
+
+    # own process: torch must initialise its HIP runtime before libidist does (see _capi.Lib)
+    if "IDIST_DEVVIEW_CHILD" not in __import__("os").environ:
+        env = dict(__import__("os").environ, IDIST_DEVVIEW_CHILD="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__ + "::test_device_views_alias_index_gpu"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        return
     import torch
 
+    torch.cuda.init()
     ida = engine_loader("gpu")
     from instant_distance_amd import dist as idd
 
