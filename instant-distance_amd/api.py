@@ -327,8 +327,9 @@ class Hnsw:
     def search_batch(self, queries, search: Search, counters: bool = False) -> BatchResult:
         """Hnsw::search (core/lib.rs:352-383) for many queries in one launch."""
         q = _as_points(queries)
-        if q.shape[0] and self.points.shape[0] and q.shape[1] != self.points.shape[1]:
-            raise TypeError(f"query dim {q.shape[1]} != index dim {self.points.shape[1]}")
+        dim = self.info().dim     # (the host copy of the points is optional: device-built / replicated indexes)
+        if q.shape[0] and len(self) and q.shape[1] != dim:
+            raise TypeError(f"query dim {q.shape[1]} != index dim {dim}")
         nq = q.shape[0]
         ef = self._ef_search
         pid = np.full((nq, ef), INVALID, dtype=np.uint32)
