@@ -510,23 +510,27 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
         if (t >= ntouched) break;
         const uint32_t pid = a.touched[t];
         wave_sync();
+        // the row and its side arrays only depend on pid: issue their loads before the (dependent) inbox walk
+        const uint32_t cur = ix.zero[(size_t)pid * kM2 + lane];
+        const uint32_t curd = a.nbr_dist[(size_t)pid * kM2 + lane];
+        const uint32_t cura = a.nbr_aux[(size_t)pid * kM2 + lane];
+        const int ns0 = (int)a.row_nsel[pid];
         // the new points that chose `pid` (inbox), nearest first
         WState ns{news, 0, kM2, 0, 0u};
         uint32_t e = a.head[pid];
         uint32_t guard = 0;
         while (e != kInvalid) {
-            const uint64_t k = ((uint64_t)a.edge_dist[e] << 32) | (a.start + e / kM2);
+            const uint32_t ed = a.edge_dist[e];
+            const uint32_t en = a.next[e];
+            const uint64_t k = ((uint64_t)ed << 32) | (a.start + e / kM2);
             const int idx = w_rank(ns, k);
             if (idx < ns.ef) w_insert(ns, idx, k);
             if (ns.plen > ns.ef) ns.plen = ns.ef;
-            e = a.next[e];
+            e = en;
             if (++guard > a.count) { status |= kStGuard; break; }
         }
         const int k_new = ns.plen;
-        const uint32_t cur = ix.zero[(size_t)pid * kM2 + lane];
-        const uint32_t curd = a.nbr_dist[(size_t)pid * kM2 + lane];
-        const int ns0 = (int)a.row_nsel[pid];
-        curaux[lane] = a.nbr_aux[(size_t)pid * kM2 + lane];
+        curaux[lane] = cura;
         const uint64_t inval = __ballot(cur == kInvalid);
         const int ncur = inval ? __builtin_ctzll(inval) : 64;
         const uint64_t key = lane < ncur ? (((uint64_t)curd << 32) | cur) : kMaxKey;

@@ -66,6 +66,26 @@ def test_search_parity_heavy_ties(eng, oracle):
     assert np.array_equal(pc.bits(got.distance), pc.bits(want.dist))
 
 
+def test_duplicate_points(eng, oracle):
+    """30 % exact duplicates: zero distances and (distance, pid) ties everywhere — build (max_batch = 1)
+    and search must still match the oracle bit for bit."""
+    ida, kind = eng
+    rng = np.random.default_rng(21)
+    n, dim = S(kind, 160, 4000), S(kind, 5, 24)
+    base = rng.random((n, dim), dtype=np.float32)
+    dup = rng.integers(0, n, size=n)
+    mask = rng.random(n) < 0.3
+    pts = np.where(mask[:, None], base[dup], base).astype(np.float32)
+    oix = oracle.Index.build(pts, oracle.default_config(ef_search=50))
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder().max_batch(1).ef_search(50))
+    zero, layers = h.into_parts()
+    assert np.array_equal(zero, oix.zero)
+    q = np.concatenate([pts[: S(kind, 6, 100)], rng.random((S(kind, 4, 100), dim), dtype=np.float32)])
+    got, want = h.search_batch(q, ida.Search(), counters=True), oix.search(q)
+    assert np.array_equal(got.pid, want.pid) and np.array_equal(got.counters, want.counters)
+    assert np.array_equal(pc.bits(got.distance), pc.bits(want.dist))
+
+
 def test_search_on_parallel_built_graph(eng, oracle):
     # graphs from the rayon-style build (core/lib.rs:316-318) are not distance-sorted per row
     ida, kind = eng
