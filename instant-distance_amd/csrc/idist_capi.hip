@@ -291,17 +291,26 @@ idist_status run_build(idist_index* ix) {
     const size_t smemB = smem_bytes_update(ix->L.nb, rt);
     if (smemB > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim %u needs %zu B of LDS per wave in the build (> 64 KiB)", ix->dim, smemB);
 
+    // step A2 tile: the new point's selected set (up to 64 rows) — it is not memory bound, so favour rows on chip
+    uint32_t rt2 = 24;
+    if (const char* e = getenv("IDIST_BUILD_RT2")) rt2 = (uint32_t)atoi(e);
+    while (rt2 > 0 && smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction) > 64 * 1024) rt2--;
+    const size_t smemA2 = smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction);
+    if (smemA2 > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim %u / ef_construction %u need %zu B of LDS per wave in the build (> 64 KiB)", ix->dim, cfg.ef_construction, smemA2);
+
     uint8_t *d_vis = nullptr, *d_gen = nullptr;
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
-    uint32_t* d_small = nullptr;           // [0] n_touched, [1..4] queue (A, B, n_slow, B2), [5] status
+    uint32_t* d_small = nullptr;           // [0] n_touched, [1..5] queue (A, B, n_slow, B2, A2), [6] status
+    uint64_t* d_wbuf = nullptr;
+    uint32_t* d_wcount = nullptr;
     uint32_t *d_row_nsel = nullptr, *d_slow = nullptr, *d_nbr_aux = nullptr;
     unsigned long long* d_stats = nullptr; // [8]
     const size_t n_edges = (size_t)cap * IDIST_M2;
     const size_t n_touch = std::min<size_t>(n_edges, n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto release = [&]() {
-        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux);
+        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount);
         hipFree(d_vis); hipFree(d_gen); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
         if (e0) hipEventDestroy(e0);
@@ -326,6 +335,8 @@ idist_status run_build(idist_index* ix) {
     BCHK(hipMalloc((void**)&d_row_nsel, (size_t)n * 4));
     BCHK(hipMemset(d_row_nsel, 0, (size_t)n * 4));
     BCHK(hipMalloc((void**)&d_slow, n_touch * 4));
+    BCHK(hipMalloc((void**)&d_wbuf, (size_t)cap * cfg.ef_construction * 8));
+    BCHK(hipMalloc((void**)&d_wcount, (size_t)cap * 4));
     BCHK(hipMalloc((void**)&d_edge_pid, n_edges * 4));
     BCHK(hipMalloc((void**)&d_edge_dist, n_edges * 4));
     BCHK(hipMalloc((void**)&d_next, n_edges * 4));
@@ -362,7 +373,10 @@ idist_status run_build(idist_index* ix) {
     a.n_touched = d_small;
     a.queue = d_small + 1;
     a.n_slow = d_small + 3;      // == &queue[2]
-    a.status = d_small + 5;
+    a.status = d_small + 6;
+    a.wbuf = d_wbuf;
+    a.wcount = d_wcount;
+    a.rt2 = rt2;
     const size_t smemF = smem_bytes_update_fast(ix->L.stride);
     const bool no_fast = getenv("IDIST_BUILD_NO_FAST") != nullptr;   // test knob: route every update through B2
     a.stats = d_stats;
@@ -386,10 +400,11 @@ idist_status run_build(idist_index* ix) {
             B = std::min(B, end - g);
             a.start = g;
             a.count = B;
-            BCHK(hipMemsetAsync(d_small, 0, 20, stream));   // n_touched, queue heads, n_slow
+            BCHK(hipMemsetAsync(d_small, 0, 24, stream));   // n_touched, queue heads, n_slow
             const uint32_t gridA = std::min(B, slots);
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
             const uint32_t gridS = std::min<uint32_t>(gridB, (uint32_t)ix->n_cu * 6);
+            const uint32_t gridA2 = std::min<uint32_t>(B, (uint32_t)ix->n_cu * 4);
             a.efc = no_fast ? 0u : cfg.ef_construction;   // efc = 0 makes the fast kernel defer everything
             BuildArgs af = a;
             a.efc = cfg.ef_construction;
@@ -399,8 +414,10 @@ idist_status run_build(idist_index* ix) {
         auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
+        auto kA2 = build_select_kernel<NB_, RS_, TAIL_>;                                           \
         IDIST_LAUNCH(kA, gridA, 64, smem, stream, view, a);                                        \
         if (cfg.has_heuristic) {                                                                   \
+            IDIST_LAUNCH(kA2, gridA2, 64, smemA2, stream, view, a);                                \
             IDIST_LAUNCH(kF, gridB, 64, smemF, stream, view, af);                                  \
             IDIST_LAUNCH(kB, gridS, 64, smemB, stream, view, a);                                   \
         } else {                                                                                   \
@@ -440,7 +457,7 @@ idist_status run_build(idist_index* ix) {
     ix->stats.seconds = ms * 1e-3;
     ix->stats.n_updates_fast = stats[6];
     ix->stats.n_updates_full = stats[7];
-    return device_status_to_code(small[5]);
+    return device_status_to_code(small[6]);
 }
 
 idist_status build_common(const void* points, bool on_device, uint32_t n, uint32_t dim, const idist_config* cfg,

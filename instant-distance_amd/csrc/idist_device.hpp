@@ -386,73 +386,13 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     }
 }
 
-// ---------------------------------------------------------------------------
-// Search::select_heuristic with extend_candidates = false (core/lib.rs:636-698).
-// Input: the first `nw` entries of st.W (sorted, = Search.nearest).  Output:
-// sel[0..return) = selected-then-backfilled keys (NOT re-sorted, Appendix A.10).
-// cq: LDS staging buffer for the candidate's own row (stride floats).
-// ---------------------------------------------------------------------------
 struct HeurCounters { uint32_t n_dist, n_rows; };
 
-template <int NB, int RS, int TAIL>
-__device__ __forceinline__ int select_heuristic(const IndexView& ix, const uint64_t* Wsrc, int nw, bool keep_pruned,
-                                                float* cq, uint64_t* sel, uint64_t* disc, uint32_t* act_pid,
-                                                uint32_t* act_dist, HeurCounters& hc, int& n_selected,
-                                                uint32_t* dprn, uint32_t* out_aux) {
-    // dprn[j] (64): pid of a selected member that pruned disc[j]; out_aux[i] (64): 0 for a selected
-    // entry of the result, else the pruner of the back-filled entry (memoised re-selection, build)
-    const int lane = lane_id();
-    int nsel = 0, ndis = 0;
-    for (int wi = 0; wi < nw; wi++) {                      // :668
-        if (nsel >= kM2) break;                            // :669-671
-        const uint64_t c = Wsrc[wi] & kKeyMask;
-        const uint32_t cd = (uint32_t)(c >> 32);
-        bool pruned = false;
-        uint32_t pr_pid = 0;
-        if (nsel > 0) {
-            // stage points[candidate.pid] (:675) once, then 8 results per wave round
-            const float* crow = ix.points + (size_t)(uint32_t)c * ix.stride;
-            for (uint32_t o = lane * 4; o < ix.stride; o += 256)
-                *reinterpret_cast<float4*>(cq + o) = *reinterpret_cast<const float4*>(crow + o);
-            hc.n_rows++;
-            wave_sync();
-            for (int b = 0; b < nsel && !pruned; b += 8) { // `any`, :676-679 (early exit per 8)
-                const int cnt = nsel - b < 8 ? nsel - b : 8;
-                if (lane < cnt) act_pid[lane] = (uint32_t)sel[b + lane];
-                wave_sync();
-                dist_rounds<NB, RS, TAIL>(ix, cq, act_pid, act_dist, cnt);
-                wave_sync();
-                hc.n_dist += (uint32_t)cnt;
-                const bool closer = lane < cnt && act_dist[lane] < cd;   // strict <, :678
-                const uint64_t cm = __ballot(closer);
-                pruned = cm != 0ull;
-                if (pruned) pr_pid = (uint32_t)sel[b + __builtin_ctzll(cm)];
-                wave_sync();
-            }
-        }
-        if (lane == 0) {                                   // :681-684
-            if (!pruned) sel[nsel] = c;
-            else if (ndis < kM2) { disc[ndis] = c; dprn[ndis] = pr_pid; }   // only the first 64 discarded can be back-filled
-        }
-        if (!pruned) nsel++; else ndis++;
-        wave_sync();
-    }
-    n_selected = nsel;
-    out_aux[lane] = 0u;
-    wave_sync();
-    if (keep_pruned) {                                     // :687-695
-        int take = kM2 - nsel;
-        if (take > ndis) take = ndis;
-        if (lane < take) { sel[nsel + lane] = disc[lane]; out_aux[nsel + lane] = dprn[lane]; }
-        if (take > 0) nsel += take;
-        wave_sync();
-    }
-    return nsel;
-}
-
-
 // ---------------------------------------------------------------------------
-// select_heuristic with the selected rows kept on chip (build step B).
+// Search::select_heuristic with extend_candidates = false (core/lib.rs:636-698), selected rows kept on
+// chip.  Input: the first `nw` entries of Wsrc (sorted, = Search.nearest).  Output: sel[0..return) =
+// selected-then-backfilled keys (NOT re-sorted); n_selected = the split point;
+// out_aux[i] = pruner pid of back-filled entry i (0 for selected ones).
 // Tile layout (LDS): blk[t][slot][32] for the full 128-B blocks, rem[slot][32]
 // for the natural-order remainder.  Slots [0, rt) hold R (the selected set, in
 // selection order), slots [rt, rt+fc) stage the next fc candidates, fetched

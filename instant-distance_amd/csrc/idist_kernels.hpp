@@ -285,26 +285,44 @@ struct BuildArgs {
     uint32_t* row_nsel;         // [n] how many leading entries of a zero row were SELECTED (the rest is back-fill)
     uint32_t* slow;             // nodes whose update needs the full re-selection (step B2)
     uint32_t* n_slow;
+    uint64_t* wbuf;             // [max_batch][efc] Search.nearest of every new point (step A -> step A2)
+    uint32_t* wcount;           // [max_batch]
     uint32_t rt;                // step B2: selected rows kept in the LDS tile
-    uint32_t* queue;            // work queue heads: [0] step A, [1] step B, [3] step B2 ([2] = n_slow)
+    uint32_t rt2;               // step A2: same for the new point's own selection
+    uint32_t* queue;            // work queue heads: [0] step A, [1] step B, [3] step B2, [4] step A2 ([2] = n_slow)
     unsigned long long* stats;  // [8] n_dist n_exp0 n_expU n_heur_dist n_heur_rows n_updates
     uint32_t* status;
 };
+
+// node.set(i, pid) for every found neighbour (core/lib.rs:516; the row was all-INVALID) and one inbox
+// record per selected neighbour for step B.
+__device__ __forceinline__ void emit_new_node(const IndexView& ix, const BuildArgs& a, uint32_t item, uint32_t nw_pid,
+                                              const uint64_t* sel, int nsel) {
+    const int lane = lane_id();
+    ix.zero[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
+    a.nbr_dist[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)(sel[lane] >> 32) : 0u;
+    if (lane < nsel) {
+        const uint64_t k = sel[lane];
+        const uint32_t e = item * kM2 + (uint32_t)lane;
+        const uint32_t pid = (uint32_t)k;
+        a.edge_pid[e] = pid;
+        a.edge_dist[e] = (uint32_t)(k >> 32);
+        const uint32_t old = atomicExch(&a.head[pid], e);
+        a.next[e] = old;
+        if (old == kInvalid) a.touched[atomicAdd(a.n_touched, 1u)] = pid;
+    }
+}
 
 template <int NB, int RS, int TAIL>
 __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArgs a) {
     IDIST_DYN_SMEM(smem_raw);
     const Smem sm = carve(smem_raw, ix.stride, a.wcap, true);
     uint64_t* sel = sm.aux + 64 + 8;
-    uint64_t* disc = sel + 64;
-    uint32_t* dprn = reinterpret_cast<uint32_t*>(sm.aux);   // the "news" area is unused in step A
-    uint32_t* out_aux = dprn + 64;
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
     Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot]};
     uint32_t status = 0;
     Counters tot{0, 0, 0};
-    HeurCounters hc{0, 0};
     for (;;) {
         uint32_t item = 0;
         if (lane == 0) item = atomicAdd(&a.queue[0], 1u);
@@ -337,32 +355,17 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
             }
         }
         const int nw = st.plen < st.ef ? st.plen : st.ef;             // Search.nearest
-        int n_selected = 0;
-        int nsel;
         if (a.has_heuristic) {
-            nsel = select_heuristic<NB, RS, TAIL>(ix, st.W, nw, a.keep_pruned != 0, sm.cq, sel, disc,
-                                                  sm.act_pid, sm.act_dist, hc, n_selected, dprn, out_aux);  // :470-472
+            // select_heuristic (:470-472) runs in step A2 with the selected rows on chip; hand Search.nearest over
+            for (int i = lane; i < nw; i += 64) a.wbuf[(size_t)item * a.efc + i] = st.W[i] & kKeyMask;
+            if (lane == 0) a.wcount[item] = (uint32_t)nw;
         } else {                                                      // select_simple, :466-469, :758-760
-            nsel = nw < kM2 ? nw : kM2;
+            const int nsel = nw < kM2 ? nw : kM2;
             if (lane < nsel) sel[lane] = st.W[lane] & kKeyMask;
-            out_aux[lane] = 0u;
-            n_selected = nsel;
             wave_sync();
-        }
-        a.nbr_aux[(size_t)nw_pid * kM2 + lane] = out_aux[lane];
-        if (lane == 0) a.row_nsel[nw_pid] = (uint32_t)n_selected;
-        // node.set(i, pid) for every found neighbour (:516); the row was all-INVALID
-        ix.zero[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
-        a.nbr_dist[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)(sel[lane] >> 32) : 0u;
-        if (lane < nsel) {
-            const uint64_t k = sel[lane];
-            const uint32_t e = item * kM2 + (uint32_t)lane;
-            const uint32_t pid = (uint32_t)k;
-            a.edge_pid[e] = pid;
-            a.edge_dist[e] = (uint32_t)(k >> 32);
-            const uint32_t old = atomicExch(&a.head[pid], e);
-            a.next[e] = old;
-            if (old == kInvalid) a.touched[atomicAdd(a.n_touched, 1u)] = pid;
+            if (lane == 0) a.row_nsel[nw_pid] = (uint32_t)nsel;
+            a.nbr_aux[(size_t)nw_pid * kM2 + lane] = 0u;
+            emit_new_node(ix, a, item, nw_pid, sel, nsel);
         }
         status |= st.status;
         wave_sync();
@@ -370,13 +373,64 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
     if (lane == 0) {
         a.gen[slot] = (uint8_t)vis.gen;
         if (status) atomicOr(a.status, status);
-        if (tot.n_dist | tot.n_exp0 | tot.n_expU | hc.n_rows) {
+        if (tot.n_dist | tot.n_exp0 | tot.n_expU) {
             atomicAdd(&a.stats[0], (unsigned long long)tot.n_dist);
             atomicAdd(&a.stats[1], (unsigned long long)tot.n_exp0);
             atomicAdd(&a.stats[2], (unsigned long long)tot.n_expU);
-            atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
-            atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Build step A2: Search::select_heuristic for the new points (core/lib.rs:470-472) on the
+// Search.nearest that step A left in wbuf, with the selected rows in an LDS tile (inside step A the
+// same selection re-gathered ~1.8 TB of selected rows from L2/HBM per 1M points, and a tile there
+// would have cost the HBM-bound descent its occupancy); then node.set + the inbox records.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline size_t smem_bytes_select(uint32_t nb, uint32_t rt, uint32_t efc) {
+    return tile_floats(nb, rt + 8) * 4 + (size_t)(efc + 8 + 64 + 64) * 8 + 4 * 64 * 4;
+}
+
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(64) void build_select_kernel(IndexView ix, BuildArgs a) {
+    IDIST_DYN_SMEM(smem_raw);
+    const int nb = NB >= 0 ? NB : (int)ix.nb;
+    Tile tile;
+    tile.rt = (int)a.rt2;
+    tile.fc = 8;
+    tile.slots = tile.rt + tile.fc;
+    tile.blk = reinterpret_cast<float*>(smem_raw);
+    tile.rem = tile.blk + (size_t)nb * tile.slots * 32;
+    uint64_t* Wl = reinterpret_cast<uint64_t*>(tile.blk + tile_floats((uint32_t)nb, (uint32_t)tile.slots));   // efc + 8
+    uint64_t* sel = Wl + a.efc + 8;
+    uint64_t* disc = sel + 64;
+    uint32_t* act_pid = reinterpret_cast<uint32_t*>(disc + 64);
+    uint32_t* act_dist = act_pid + 64;
+    uint32_t* dprn = act_dist + 64;
+    uint32_t* out_aux = dprn + 64;
+    const int lane = lane_id();
+    HeurCounters hc{0, 0};
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(&a.queue[4], 1u);
+        item = uniform_u32(item);
+        if (item >= a.count) break;
+        const uint32_t nw_pid = a.start + item;
+        const int nw = (int)a.wcount[item];
+        wave_sync();
+        for (int i = lane; i < nw; i += 64) Wl[i] = a.wbuf[(size_t)item * a.efc + i];
+        wave_sync();
+        int n_selected = 0;
+        const int nsel = select_heuristic_tiled<NB, RS, TAIL>(ix, Wl, nw, a.keep_pruned != 0, tile, sel, disc, act_pid,
+                                                              act_dist, hc, n_selected, dprn, out_aux);
+        if (lane == 0) a.row_nsel[nw_pid] = (uint32_t)n_selected;
+        a.nbr_aux[(size_t)nw_pid * kM2 + lane] = out_aux[lane];
+        emit_new_node(ix, a, item, nw_pid, sel, nsel);
+        wave_sync();
+    }
+    if (lane == 0 && (hc.n_dist | hc.n_rows)) {
+        atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
+        atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);
     }
 }
 
