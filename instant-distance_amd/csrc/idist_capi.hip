@@ -292,7 +292,7 @@ idist_status run_build(idist_index* ix) {
     if (smemB > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim %u needs %zu B of LDS per wave in the build (> 64 KiB)", ix->dim, smemB);
 
     // step A2 tile: the new point's selected set (up to 64 rows) — it is not memory bound, so favour rows on chip
-    uint32_t rt2 = 24;
+    uint32_t rt2 = 16;
     if (const char* e = getenv("IDIST_BUILD_RT2")) rt2 = (uint32_t)atoi(e);
     while (rt2 > 0 && smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction) > 64 * 1024) rt2--;
     const size_t smemA2 = smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction);
