@@ -302,7 +302,7 @@ idist_status run_build(idist_index* ix) {
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
     uint32_t* d_small = nullptr;           // [0] n_touched, [1..5] queue (A, B, n_slow, B2, A2), [6] status
-    uint64_t* d_wbuf = nullptr;
+    uint64_t *d_wbuf = nullptr, *d_dlog = nullptr;
     uint32_t* d_wcount = nullptr;
     uint32_t *d_row_nsel = nullptr, *d_slow = nullptr, *d_nbr_aux = nullptr;
     unsigned long long* d_stats = nullptr; // [8]
@@ -310,7 +310,7 @@ idist_status run_build(idist_index* ix) {
     const size_t n_touch = std::min<size_t>(n_edges, n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto release = [&]() {
-        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount);
+        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount); hipFree(d_dlog);
         hipFree(d_vis); hipFree(d_gen); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
         if (e0) hipEventDestroy(e0);
@@ -337,6 +337,7 @@ idist_status run_build(idist_index* ix) {
     BCHK(hipMalloc((void**)&d_slow, n_touch * 4));
     BCHK(hipMalloc((void**)&d_wbuf, (size_t)cap * cfg.ef_construction * 8));
     BCHK(hipMalloc((void**)&d_wcount, (size_t)cap * 4));
+    BCHK(hipMalloc((void**)&d_dlog, (size_t)cap * kDlogCap * 8));
     BCHK(hipMalloc((void**)&d_edge_pid, n_edges * 4));
     BCHK(hipMalloc((void**)&d_edge_dist, n_edges * 4));
     BCHK(hipMalloc((void**)&d_next, n_edges * 4));
@@ -374,6 +375,7 @@ idist_status run_build(idist_index* ix) {
     a.queue = d_small + 1;
     a.n_slow = d_small + 3;      // == &queue[2]
     a.status = d_small + 6;
+    a.dlog = d_dlog;
     a.wbuf = d_wbuf;
     a.wcount = d_wcount;
     a.rt2 = rt2;
@@ -401,6 +403,7 @@ idist_status run_build(idist_index* ix) {
             a.start = g;
             a.count = B;
             BCHK(hipMemsetAsync(d_small, 0, 24, stream));   // n_touched, queue heads, n_slow
+            BCHK(hipMemsetAsync(d_dlog, 0xFF, (size_t)B * kDlogCap * 8, stream));   // empty distance logs
             const uint32_t gridA = std::min(B, slots);
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
             const uint32_t gridS = std::min<uint32_t>(gridB, (uint32_t)ix->n_cu * 6);

@@ -287,6 +287,36 @@ __device__ __forceinline__ void w_cull(WState& st) {
 }
 
 // ---------------------------------------------------------------------------
+// Distance log of one insertion (build only): every distance the descent computes is remembered in a
+// small open-addressing table (key = dist_bits << 32 | pid) so that the neighbour re-selection of
+// step B can look d(new, r) up instead of gathering row r again.  A miss is always legal (the caller
+// recomputes), so a full table just drops entries.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kDlogBits = 14;                     // 16384 slots (128 KB) per insertion in flight
+constexpr uint32_t kDlogCap = 1u << kDlogBits;
+constexpr uint64_t kDlogEmpty = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint32_t kDlogMiss = 0xFFFFFFFFu;            // never a canonical distance pattern
+__device__ __forceinline__ uint32_t dlog_slot(uint32_t pid) { return (pid * 0x9E3779B1u) >> (32 - kDlogBits); }
+__device__ __forceinline__ void dlog_insert(uint64_t* T, uint64_t key) {
+    uint32_t sl = dlog_slot((uint32_t)key);
+    for (int probe = 0; probe < 32; probe++) {
+        const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(T + sl), kDlogEmpty, key);
+        if (old == kDlogEmpty || (uint32_t)old == (uint32_t)key) return;
+        sl = (sl + 1) & (kDlogCap - 1);
+    }
+}
+__device__ __forceinline__ uint32_t dlog_find(const uint64_t* T, uint32_t pid) {
+    uint32_t sl = dlog_slot(pid);
+    for (int probe = 0; probe < 32; probe++) {
+        const uint64_t e = T[sl];
+        if (e == kDlogEmpty) return kDlogMiss;
+        if ((uint32_t)e == pid) return (uint32_t)(e >> 32);
+        sl = (sl + 1) & (kDlogCap - 1);
+    }
+    return kDlogMiss;
+}
+
+// ---------------------------------------------------------------------------
 // Visited (core/types.rs:13-59) in HBM: one byte per point, per slot.
 // ---------------------------------------------------------------------------
 struct Visited {
@@ -310,13 +340,16 @@ struct Counters { uint32_t n_dist, n_exp0, n_expU; };
 // Search::push for the very first entry point (core/lib.rs:364, :444)
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, WState& st, Visited& vis,
-                                           uint32_t* act_pid, uint32_t* act_dist, Counters& ctr) {
+                                           uint32_t* act_pid, uint32_t* act_dist, Counters& ctr, uint64_t* dlog = nullptr) {
     const int lane = lane_id();
     if (lane == 0) { act_pid[0] = 0u; vis.store[0] = (uint8_t)vis.gen; }
     wave_sync();
     dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, 1);
     wave_sync();
-    if (lane == 0) st.W[0] = ((uint64_t)act_dist[0] << 32);  // pid 0
+    if (lane == 0) {
+        st.W[0] = ((uint64_t)act_dist[0] << 32);  // pid 0
+        if (dlog) dlog_insert(dlog, (uint64_t)act_dist[0] << 32);
+    }
     wave_sync();
     st.plen = 1;
     st.cursor = 0;
@@ -330,7 +363,7 @@ __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, 
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t* rows, int row_stride, int links,
                                              const float* q, WState& st, Visited& vis, uint32_t* act_pid,
-                                             uint32_t* act_dist, Counters& ctr, bool is_zero) {
+                                             uint32_t* act_dist, Counters& ctr, bool is_zero, uint64_t* dlog = nullptr) {
     const int lane = lane_id();
     uint32_t guard = 0;
     for (;;) {
@@ -370,6 +403,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             ctr.n_dist += (uint32_t)na;
             uint64_t key = kMaxKey;
             if (lane < na) key = ((uint64_t)act_dist[lane] << 32) | act_pid[lane];
+            if (dlog && lane < na) dlog_insert(dlog, key);
             // entries that cannot have rank < ef even now never will (W only improves)
             const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
             uint64_t pm = __ballot(lane < na && key < thr);

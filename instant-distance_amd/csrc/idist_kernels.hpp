@@ -285,6 +285,7 @@ struct BuildArgs {
     uint32_t* row_nsel;         // [n] how many leading entries of a zero row were SELECTED (the rest is back-fill)
     uint32_t* slow;             // nodes whose update needs the full re-selection (step B2)
     uint32_t* n_slow;
+    uint64_t* dlog;             // [max_batch][kDlogCap] distances computed by each new point's descent
     uint64_t* wbuf;             // [max_batch][efc] Search.nearest of every new point (step A -> step A2)
     uint32_t* wcount;           // [max_batch]
     uint32_t rt;                // step B2: selected rows kept in the LDS tile
@@ -337,20 +338,21 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
         wave_sync();
 
         WState st{sm.W, 0, 1, 0, 0u};
+        uint64_t* dlog = a.dlog + (size_t)item * kDlogCap;
         visited_clear(vis);                                           // search.reset(), :443
-        push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot);  // :444
+        push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, dlog);  // :444
         const int num = a.layer == 0 ? kM2 : kM;                      // :445
         for (int cur = (int)a.top;; cur--) {                          // :447
             st.ef = cur <= (int)a.layer ? (int)a.efc : 1;             // :448-452
             if (cur > (int)a.layer) {                                 // :453-457
                 const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-                search_layer<NB, RS, TAIL>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false);
+                search_layer<NB, RS, TAIL>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dlog);
                 w_cull(st);
                 visited_clear(vis);
                 for (int i = lane; i < st.plen; i += 64) vis.store[(uint32_t)st.W[i]] = (uint8_t)vis.gen;
                 wave_sync();
             } else {                                                  // :458-461
-                search_layer<NB, RS, TAIL>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0);
+                search_layer<NB, RS, TAIL>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dlog);
                 break;
             }
         }
@@ -533,7 +535,7 @@ constexpr int kMaxNewFast = 8;
 constexpr int kFastX = 80;   // columns of the new-vs-{old selected, new} distance table
 __host__ __device__ inline size_t smem_bytes_update_fast(uint32_t stride) {
     return (size_t)stride * 4 + (size_t)(kUpdW + 72 + 64 + 64 + 64) * 8 +
-           (size_t)(kUpdW + kFastX + kMaxNewFast * kFastX + 64 + kMaxNewFast + 64 + 64) * 4;
+           (size_t)(kUpdW + kFastX + kMaxNewFast * kFastX + 64 + kMaxNewFast + 64 + 64 + 3 * kFastX) * 4;
 }
 
 template <int NB, int RS, int TAIL>
@@ -552,6 +554,9 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
     uint32_t* addx = Rx + 64;                                   // active points that entered R
     uint32_t* dprn = addx + kMaxNewFast;                        // pruner of disc[j]
     uint32_t* curaux = dprn + 64;                               // stored pruners of the current row
+    uint32_t* act_x = curaux + 64;                              // columns whose distance must be gathered
+    uint32_t* act_p = act_x + kFastX;                           // ... their pids
+    uint32_t* act_d = act_p + kFastX;                           // ... the results
     enum : uint32_t { OLD_SEL = 0, OLD_DISC = 1, NEW = 2 };
     const int lane = lane_id();
     const uint32_t ntouched = *a.n_touched;
@@ -608,18 +613,44 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             if (lane < ncur) { W[ra] = key; kindx[ra] = ((lane < ns0 ? OLD_SEL : OLD_DISC) << 8) | (uint32_t)lane; }
             if (lane < k_new) { W[rb] = keyb; kindx[rb] = (NEW << 8) | (uint32_t)(ns0 + lane); }
             wave_sync();
-            // distances of every new point to {old selected} U {new}  (Point::distance is symmetric bit for bit)
+            // distances of every new point to {old selected} U {new}: the new point's own descent (step A)
+            // computed almost all of them — every member of its final W was expanded, so every entry of
+            // their rows was visited — and logged them; only the misses (rows seen through a 32-link
+            // upper-layer expansion, other new points of this step) are gathered again.
             const int nx = ns0 + k_new;
             for (int ai = 0; ai < k_new; ai++) {
-                const float* prow = ix.points + (size_t)(uint32_t)news[ai] * ix.stride;
-                for (uint32_t o = lane * 4; o < ix.stride; o += 256)
-                    *reinterpret_cast<float4*>(cq + o) = *reinterpret_cast<const float4*>(prow + o);
+                const uint32_t a_pid = (uint32_t)news[ai];
+                const uint64_t* T = a.dlog + (size_t)(a_pid - a.start) * kDlogCap;
+                uint32_t dv = kDlogMiss;
+                if (lane < ns0) dv = dlog_find(T, X[lane]);
+                if (lane < ns0) Dn[ai * kFastX + lane] = dv;
+                int nmiss = 0;
+                // columns [0, ns0) that missed + the other new points: gather those rows
+                const uint64_t mm = __ballot(lane < ns0 && dv == kDlogMiss);
+                const int n0 = __popcll(mm);
+                if (lane < ns0 && dv == kDlogMiss) {
+                    const int at = __popcll(mm & ((1ull << lane) - 1ull));
+                    act_x[at] = (uint32_t)lane;
+                }
+                if (lane < k_new) act_x[n0 + lane] = (uint32_t)(ns0 + lane);
+                nmiss = n0 + k_new;
                 wave_sync();
-                dist_rounds<NB, RS, TAIL>(ix, cq, X, Dn + ai * kFastX, nx);
-                wave_sync();
-                hc.n_dist += (uint32_t)nx;
-                hc.n_rows += 1;
+                if (nmiss > (k_new > 1 ? 0 : 1) || n0 > 0) {
+                    // (with a single new point and no miss nothing is needed: the self column is never read)
+                    for (int i = lane; i < nmiss; i += 64) act_p[i] = X[act_x[i]];
+                    const float* prow = ix.points + (size_t)a_pid * ix.stride;
+                    for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+                        *reinterpret_cast<float4*>(cq + o) = *reinterpret_cast<const float4*>(prow + o);
+                    wave_sync();
+                    dist_rounds<NB, RS, TAIL>(ix, cq, act_p, act_d, nmiss);
+                    wave_sync();
+                    for (int i = lane; i < nmiss; i += 64) Dn[ai * kFastX + act_x[i]] = act_d[i];
+                    hc.n_dist += (uint32_t)nmiss;
+                    hc.n_rows += 1;
+                    wave_sync();
+                }
             }
+            (void)nx;
             // replay of select_heuristic (core/lib.rs:668-685) on stored verdicts
             int nAdd = 0, nAct = k_new;
             for (int i = 0; i < total; i++) {
