@@ -276,7 +276,8 @@ idist_status run_build(idist_index* ix) {
     if (n <= 1) return IDIST_OK;   // pid 0 is never inserted (core/lib.rs:279-280)
     const idist_config& cfg = ix->cfg;
     const uint32_t top = ix->n_upper;
-    const uint32_t cap = cfg.max_batch == 0 ? 8192u : cfg.max_batch;
+    // a step never holds more than 1/32 of the points already inserted, so scratch is sized by that
+    const uint32_t cap = std::min<uint32_t>(cfg.max_batch == 0 ? 8192u : cfg.max_batch, std::max<uint32_t>(1u, n / 32u));
     const uint32_t slots_max = default_slots(ix);
     const uint32_t slots = std::min(cap, slots_max);
     const size_t vis_stride = ((size_t)n + 255) & ~(size_t)255;
