@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gt-queries", type=int, default=0, help="queries with exact ground truth (0 = all; MFMA -2QP^T filter + exact re-rank)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries for the CPU baseline (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-build-sample", type=int, default=40_000, help="points of the prefix the CPU oracle builds (threaded)")
+    ap.add_argument("--cpu-build-sample", type=int, default=100_000, help="points of the prefix the CPU oracle builds (threaded)")
     ap.add_argument("--max-batch", type=int, default=0)
     args = ap.parse_args()
 
