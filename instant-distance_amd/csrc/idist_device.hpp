@@ -86,6 +86,14 @@ __device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// value of lane `src` (src must be wave-uniform): v_readlane_b32, no LDS round trip
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int src) {
+#ifdef IDIST_EMU
+    return bcast_u32(v, src);
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
+#endif
+}
 
 __device__ __forceinline__ uint32_t canon_bits(float r, uint32_t metric) {
     if (metric) r = __builtin_sqrtf(r);      // tests/all.rs:96; correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)

@@ -651,27 +651,46 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
                 }
             }
             (void)nx;
-            // replay of select_heuristic (core/lib.rs:668-685) on stored verdicts
+            // replay of select_heuristic (core/lib.rs:668-685) on stored verdicts.  Candidate i lives in
+            // lane i & 63 (two registers per lane cover the <= 128 candidates); R, the discarded list and the
+            // added set are register-resident too (entry j in lane j), so an iteration is readlanes + a ballot.
+            wave_sync();
+            uint32_t cw_lo[2], cw_hi[2], ckx[2];
+            for (int h = 0; h < 2; h++) {
+                const int i = h * 64 + lane;
+                const uint64_t v = i < total ? W[i] : 0ull;
+                cw_lo[h] = (uint32_t)v;
+                cw_hi[h] = (uint32_t)(v >> 32);
+                ckx[h] = i < total ? kindx[i] : 0u;
+            }
+            uint32_t r_pid = kInvalid, r_x = 0;        // lane j: R[j]
+            uint32_t s_lo = 0, s_hi = 0;               // lane j: sel[j] (key)
+            uint32_t d_lo = 0, d_hi = 0, d_pr = 0;     // lane j: disc[j] (key, pruner)
+            uint32_t add_a = 0;                        // lane j: index of the j-th active point that entered R
             int nAdd = 0, nAct = k_new;
             for (int i = 0; i < total; i++) {
                 if (nR >= kM2) break;                                   // :669-671
-                const uint64_t c = W[i];
-                const uint32_t kx = kindx[i];
+                const int h = i >> 6, li = i & 63;
+                const uint32_t c_lo = readlane_u32(h ? cw_lo[1] : cw_lo[0], li);
+                const uint32_t cd = readlane_u32(h ? cw_hi[1] : cw_hi[0], li);
+                const uint32_t kx = readlane_u32(h ? ckx[1] : ckx[0], li);
                 const uint32_t kind = kx >> 8, x = kx & 255u;
-                const uint32_t cd = (uint32_t)(c >> 32);
                 bool pruned;
                 uint32_t pr_pid = 0, cx = x;
                 if (kind == OLD_SEL) {
                     // passed every older selected member already: only members added since can prune it
-                    bool closer = false;
-                    if (lane < nAdd) closer = Dn[addx[lane] * kFastX + x] < cd;          // strict <, :678
-                    const uint64_t cm = __ballot(closer);
-                    pruned = cm != 0ull;
-                    if (pruned) pr_pid = X[ns0 + addx[__builtin_ctzll(cm)]];
+                    pruned = false;
+                    if (nAdd > 0) {
+                        bool closer = false;
+                        if (lane < nAdd) closer = Dn[add_a * kFastX + x] < cd;           // strict <, :678
+                        const uint64_t cm = __ballot(closer);
+                        pruned = cm != 0ull;
+                        if (pruned) pr_pid = X[ns0 + readlane_u32(add_a, __builtin_ctzll(cm))];
+                    }
                 } else if (kind == OLD_DISC) {
                     // stays discarded while the member that pruned it is still selected
                     const uint32_t p = curaux[x];
-                    const bool still = __ballot(lane < nR && (uint32_t)sel[lane] == p) != 0ull;
+                    const bool still = __ballot(lane < nR && r_pid == p) != 0ull;
                     if (still) {
                         pruned = true;
                         pr_pid = p;
@@ -679,8 +698,8 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
                         // its pruner is gone: evaluate it like a new point against the current selected set
                         if (nAct >= kMaxNewFast) { defer = true; break; }
                         const int ci = nAct++;
-                        if (lane == 0) X[ns0 + ci] = (uint32_t)c;
-                        const float* prow = ix.points + (size_t)(uint32_t)c * ix.stride;
+                        if (lane == 0) X[ns0 + ci] = c_lo;
+                        const float* prow = ix.points + (size_t)c_lo * ix.stride;
                         for (uint32_t o = lane * 4; o < ix.stride; o += 256)
                             *reinterpret_cast<float4*>(cq + o) = *reinterpret_cast<const float4*>(prow + o);
                         wave_sync();
@@ -689,40 +708,42 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
                         hc.n_dist += (uint32_t)(ns0 + ci);
                         hc.n_rows += 1;
                         bool closer = false;
-                        if (lane < nR) closer = Dn[ci * kFastX + Rx[lane]] < cd;          // columns of all earlier actives exist
+                        if (lane < nR) closer = Dn[ci * kFastX + r_x] < cd;             // columns of all earlier actives exist
                         const uint64_t cm = __ballot(closer);
                         pruned = cm != 0ull;
-                        if (pruned) pr_pid = (uint32_t)sel[__builtin_ctzll(cm)];
+                        if (pruned) pr_pid = readlane_u32(r_pid, __builtin_ctzll(cm));
                         cx = (uint32_t)(ns0 + ci);
                     }
                 } else {
                     const uint32_t ai = x - (uint32_t)ns0;
                     bool closer = false;
                     if (lane < nR) {
-                        const uint32_t xr = Rx[lane];
                         // distance between two active points: the row of the later-activated one has the column
-                        const uint32_t dv = (xr < (uint32_t)ns0 || xr - (uint32_t)ns0 < ai) ? Dn[ai * kFastX + xr]
-                                                                                          : Dn[(xr - (uint32_t)ns0) * kFastX + x];
+                        const uint32_t dv = (r_x < (uint32_t)ns0 || r_x - (uint32_t)ns0 < ai) ? Dn[ai * kFastX + r_x]
+                                                                                            : Dn[(r_x - (uint32_t)ns0) * kFastX + x];
                         closer = dv < cd;
                     }
                     const uint64_t cm = __ballot(closer);
                     pruned = cm != 0ull;
-                    if (pruned) pr_pid = (uint32_t)sel[__builtin_ctzll(cm)];
+                    if (pruned) pr_pid = readlane_u32(r_pid, __builtin_ctzll(cm));
                 }
-                wave_sync();
-                if (lane == 0) {
-                    if (!pruned) {
-                        sel[nR] = c;
-                        Rx[nR] = cx;
-                        if (cx >= (uint32_t)ns0) addx[nAdd] = cx - (uint32_t)ns0;
-                    } else if (nD < kM2) {
-                        disc[nD] = c;
-                        dprn[nD] = pr_pid;
+                if (!pruned) {
+                    if (lane == nR) { s_lo = c_lo; s_hi = cd; r_pid = c_lo; r_x = cx; }
+                    if (cx >= (uint32_t)ns0) {
+                        if (lane == nAdd) add_a = cx - (uint32_t)ns0;
+                        nAdd++;
                     }
+                    nR++;
+                } else {
+                    if (lane == nD) { d_lo = c_lo; d_hi = cd; d_pr = pr_pid; }   // nD < 64 whenever it matters (back-fill room)
+                    nD++;
                 }
-                if (!pruned) { nR++; if (cx >= (uint32_t)ns0) nAdd++; } else { nD++; }
-                wave_sync();
             }
+            // hand the register-resident lists to the common tail below
+            wave_sync();
+            if (lane < nR) sel[lane] = ((uint64_t)s_hi << 32) | s_lo;
+            if (lane < nD && lane < kM2) { disc[lane] = ((uint64_t)d_hi << 32) | d_lo; dprn[lane] = d_pr; }
+            wave_sync();
         }
         if (defer) {
             // leave the inbox in place; step B2 redoes this node from scratch
