@@ -302,6 +302,8 @@ __device__ __forceinline__ void emit_new_node(const IndexView& ix, const BuildAr
     const int lane = lane_id();
     ix.zero[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)sel[lane] : kInvalid;
     a.nbr_dist[(size_t)nw_pid * kM2 + lane] = lane < nsel ? (uint32_t)(sel[lane] >> 32) : 0u;
+    bool first = false;
+    uint32_t my_pid = 0;
     if (lane < nsel) {
         const uint64_t k = sel[lane];
         const uint32_t e = item * kM2 + (uint32_t)lane;
@@ -310,7 +312,16 @@ __device__ __forceinline__ void emit_new_node(const IndexView& ix, const BuildAr
         a.edge_dist[e] = (uint32_t)(k >> 32);
         const uint32_t old = atomicExch(&a.head[pid], e);
         a.next[e] = old;
-        if (old == kInvalid) a.touched[atomicAdd(a.n_touched, 1u)] = pid;
+        first = old == kInvalid;
+        my_pid = pid;
+    }
+    // one atomic per wave, not per edge: a single word saturates at ~88 atomics/us (MI355X_MICROARCH.md, "dequeue")
+    const uint64_t fm = __ballot(first);
+    if (fm) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.n_touched, (uint32_t)__popcll(fm));
+        base = uniform_u32(base);
+        if (first) a.touched[base + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = my_pid;
     }
 }
 
@@ -562,11 +573,20 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
     const uint32_t ntouched = *a.n_touched;
     HeurCounters hc{0, 0};
     uint32_t updates = 0, deferred = 0, status = 0;
+    // items per dequeue: 37 M updates through one counter would cost ~0.4 s; small steps keep 1 item per wave
+    uint32_t kChunk = ntouched / (gridDim.x * 4u);
+    kChunk = kChunk < 1u ? 1u : (kChunk > 16u ? 16u : kChunk);
+    uint32_t t_next = 0, t_end = 0;
     for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(&a.queue[1], 1u);
-        t = uniform_u32(t);
-        if (t >= ntouched) break;
+        if (t_next == t_end) {
+            uint32_t t0 = 0;
+            if (lane == 0) t0 = atomicAdd(&a.queue[1], kChunk);
+            t0 = uniform_u32(t0);
+            if (t0 >= ntouched) break;
+            t_next = t0;
+            t_end = t0 + kChunk < ntouched ? t0 + kChunk : ntouched;
+        }
+        const uint32_t t = t_next++;
         const uint32_t pid = a.touched[t];
         wave_sync();
         // the row and its side arrays only depend on pid: issue their loads before the (dependent) inbox walk
