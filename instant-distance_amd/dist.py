@@ -79,15 +79,31 @@ def replicate_index(hnsw: Hnsw | None, builder: Builder, src: int = 0, chunk_byt
     n, dim, n_upper, ef = int(meta[0]), int(meta[1]), int(meta[2]), int(meta[3])
     layer_len = np.ascontiguousarray(meta[8:8 + n_upper].astype(np.uint32))
 
+    def _all_ok(ok: bool) -> bool:
+        """every rank must have finished its LOCAL preparation before the first bulk collective, otherwise a
+        rank that failed locally would leave the others blocked inside the broadcast"""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     if dist.get_backend() == "nccl":
         dev = torch.device("cuda", torch.cuda.current_device())
-        if rank != src:
-            cfg = builder._config()
-            cfg.ef_search = ef
-            h = C.c_void_p()
-            L.check(L.idist_index_alloc(n, dim, C.byref(cfg), _capi.u32p(layer_len), n_upper, dev.index, C.byref(h)))
-            hnsw = Hnsw(h, np.zeros((n, 0), dtype=np.float32), ef)   # host copy of the points is not replicated
-        for t in device_views(hnsw, dev):
+        views, err = None, None
+        try:
+            if rank != src:
+                cfg = builder._config()
+                cfg.ef_search = ef
+                h = C.c_void_p()
+                L.check(L.idist_index_alloc(n, dim, C.byref(cfg), _capi.u32p(layer_len), n_upper, dev.index, C.byref(h)))
+                hnsw = Hnsw(h, np.zeros((n, 0), dtype=np.float32), ef)   # host copy of the points is not replicated
+            views = device_views(hnsw, dev)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        if not _all_ok(err is None):
+            raise RuntimeError(f"replicate_index: local preparation failed on some rank (this rank: {err!r})")
+        for t in views:
             if t is None:
                 continue
             for off in range(0, t.numel(), chunk_bytes):
