@@ -96,3 +96,14 @@ def test_replicate_and_shard_world2(oracle):
     assert (got[0][1], got[0][2], got[1][1], got[1][2]) == (0, 15, 15, 31)
     assert np.array_equal(pid, want.pid) and np.array_equal(cnt, want.count)
     assert np.array_equal(dist_.view(np.uint32), want.dist.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_replicate_gpu():
+    """backend nccl (= RCCL) on the real GPU with one rank: meta broadcast + bulk broadcast straight out of the
+    library-owned device buffers (zero-copy views).  Own process: torch must bring up its HIP runtime first."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "nccl_selftest.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "nccl selftest ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
