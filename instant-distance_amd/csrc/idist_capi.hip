@@ -63,10 +63,6 @@ Layout make_layout(uint32_t dim) {
     L.rs = steps % 4u;
     const uint32_t used = 32u * L.nb + 8u * L.rs + 4u * L.tail;
     L.stride = std::max(16u, (used + 15u) & ~15u);
-    if (const char* e = getenv("IDIST_ROW_ALIGN_FLOATS")) {   // experiment knob: pad rows to a coarser boundary
-        const uint32_t al = (uint32_t)atoi(e);
-        if (al >= 16 && (al & (al - 1)) == 0) L.stride = (L.stride + al - 1) & ~(al - 1);
-    }
     return L;
 }
 
@@ -876,13 +872,12 @@ idist_status idist_distance_batch(const idist_index* idx, const float* queries, 
     }
     const uint32_t chunks = (n_ids + 63u) / 64u;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)nq * chunks, 1u << 20);
-    const int x2 = getenv("IDIST_DIST_X2") ? atoi(getenv("IDIST_DIST_X2")) : 0;   // experiment: two rounds of loads in flight
     const size_t smem = smem_bytes(idx->L.stride, 0, false);
     IndexView view = idx->view();
 #define LAUNCH_DIST(NB_, RS_, TAIL_)                                                              \
     {                                                                                             \
         auto kD = distance_batch_kernel<NB_, RS_, TAIL_>;                                         \
-        IDIST_LAUNCH(kD, grid, 64, smem, (hipStream_t) nullptr, view, d_q, nq, d_ids, n_ids, d_out, x2); \
+        IDIST_LAUNCH(kD, grid, 64, smem, (hipStream_t) nullptr, view, d_q, nq, d_ids, n_ids, d_out); \
     }
     IDIST_DISPATCH(idx->L, LAUNCH_DIST);
 #undef LAUNCH_DIST

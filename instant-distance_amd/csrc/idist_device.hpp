@@ -66,17 +66,7 @@ __host__ __device__ inline uint32_t blocked_pos(uint32_t e, uint32_t nb) {
     return e;
 }
 
-// 16-byte load of point-row data.  Rows are streamed once per use and never re-read by the same CU, so
-// the build can mark them non-temporal (IDIST_NT=1) to keep adjacency rows / visited bytes in L2.
-#if defined(IDIST_NT) && !defined(IDIST_EMU)
-typedef float idist_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ldg_row4(const float* p) {
-    const idist_v4f v = __builtin_nontemporal_load(reinterpret_cast<const idist_v4f*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-#else
 __device__ __forceinline__ float4 ldg_row4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-#endif
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }  // single-wave workgroup
@@ -185,67 +175,6 @@ template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q, const uint32_t* act_pid,
                                             uint32_t* act_dist, int na) {
     dist_rounds<NB, RS, TAIL>(ix, natural_view(q, NB >= 0 ? NB : (int)ix.nb), act_pid, act_dist, na);
-}
-
-// ---------------------------------------------------------------------------
-// dist_rounds with TWO rounds (16 rows) of loads in flight per wave before the first FMA — an experiment
-// on memory-level parallelism (static geometry only; same arithmetic, same results).
-// ---------------------------------------------------------------------------
-template <int NB, int RS, int TAIL>
-__device__ __forceinline__ void dist_rounds_x2(const IndexView& ix, const float* q, const uint32_t* act_pid,
-                                               uint32_t* act_dist, int na) {
-    static_assert(NB >= 0 && NB <= 12, "static geometry with <= 12 blocks");
-    constexpr int NBB = NB > 0 ? NB : 1;
-    const int lane = lane_id();
-    const int g = lane >> 3, j = lane & 7;
-    for (int base = 0; base < na; base += 16) {
-        const int k0 = base + g, k1 = base + 8 + g;
-        const bool on0 = k0 < na, on1 = k1 < na;
-        const float* row0 = ix.points + (size_t)(on0 ? act_pid[k0] : 0u) * ix.stride;
-        const float* row1 = ix.points + (size_t)(on1 ? act_pid[k1] : 0u) * ix.stride;
-        float4 p0[NBB], p1[NBB];
-        float r0[4], r1[4];
-#pragma unroll
-        for (int t = 0; t < NB; t++) p0[t] = ldg_row4(row0 + t * 32 + j * 4);
-#pragma unroll
-        for (int c = 0; c < RS; c++) r0[c] = row0[NB * 32 + c * 8 + j];
-        if (TAIL) r0[3] = row0[NB * 32 + RS * 8 + (j & 3)];
-#pragma unroll
-        for (int t = 0; t < NB; t++) p1[t] = ldg_row4(row1 + t * 32 + j * 4);
-#pragma unroll
-        for (int c = 0; c < RS; c++) r1[c] = row1[NB * 32 + c * 8 + j];
-        if (TAIL) r1[3] = row1[NB * 32 + RS * 8 + (j & 3)];
-        float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll
-        for (int t = 0; t < NB; t++) {
-            const float4 w = *reinterpret_cast<const float4*>(q + t * 32 + j * 4);
-            float d;
-            d = w.x - p0[t].x; acc0 = __builtin_fmaf(d, d, acc0);
-            d = w.y - p0[t].y; acc0 = __builtin_fmaf(d, d, acc0);
-            d = w.z - p0[t].z; acc0 = __builtin_fmaf(d, d, acc0);
-            d = w.w - p0[t].w; acc0 = __builtin_fmaf(d, d, acc0);
-            d = w.x - p1[t].x; acc1 = __builtin_fmaf(d, d, acc1);
-            d = w.y - p1[t].y; acc1 = __builtin_fmaf(d, d, acc1);
-            d = w.z - p1[t].z; acc1 = __builtin_fmaf(d, d, acc1);
-            d = w.w - p1[t].w; acc1 = __builtin_fmaf(d, d, acc1);
-        }
-#pragma unroll
-        for (int c = 0; c < RS; c++) {
-            const float qq = q[NB * 32 + c * 8 + j];
-            float d = qq - r0[c]; acc0 = __builtin_fmaf(d, d, acc0);
-            d = qq - r1[c]; acc1 = __builtin_fmaf(d, d, acc1);
-        }
-        float a0 = acc0 + __shfl_xor(acc0, 4, 64), a1 = acc1 + __shfl_xor(acc1, 4, 64);
-        if (TAIL) {
-            const float qq = q[NB * 32 + RS * 8 + (j & 3)];
-            float d = qq - r0[3]; a0 = __builtin_fmaf(d, d, a0);
-            d = qq - r1[3]; a1 = __builtin_fmaf(d, d, a1);
-        }
-        const float s0 = a0 + __shfl_xor(a0, 2, 64), s1 = a1 + __shfl_xor(a1, 2, 64);
-        const float f0 = s0 + __shfl_xor(s0, 1, 64), f1 = s1 + __shfl_xor(s1, 1, 64);
-        if (on0 && j == 0) act_dist[k0] = canon_bits(f0, ix.metric);
-        if (on1 && j == 0) act_dist[k1] = canon_bits(f1, ix.metric);
-    }
 }
 
 // ---------------------------------------------------------------------------

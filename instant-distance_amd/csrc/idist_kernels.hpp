@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) 
 template <int NB, int RS, int TAIL>
 __global__ __launch_bounds__(64) void distance_batch_kernel(IndexView ix, const float* __restrict__ queries, uint32_t nq,
                                                            const uint32_t* __restrict__ ids, uint32_t n_ids,
-                                                           float* __restrict__ out, int x2) {
+                                                           float* __restrict__ out) {
     IDIST_DYN_SMEM(smem_raw);
     const Smem sm = carve(smem_raw, ix.stride, 0, false);
     const int lane = lane_id();
@@ -197,12 +197,7 @@ __global__ __launch_bounds__(64) void distance_batch_kernel(IndexView ix, const 
         const int my = __popcll(m & ((1ull << lane) - 1ull));
         if (ok) sm.act_pid[my] = id;
         wave_sync();
-        if constexpr (NB >= 0 && NB <= 12) {
-            if (x2) dist_rounds_x2<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, __popcll(m));
-            else dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, __popcll(m));
-        } else {
-            dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, __popcll(m));
-        }
+        dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, __popcll(m));
         wave_sync();
         if (i < n_ids) out[(size_t)qi * n_ids + i] = ok ? __uint_as_float(sm.act_dist[my]) : __uint_as_float(0x7f800000u);
     }
