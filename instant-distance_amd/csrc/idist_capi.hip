@@ -258,6 +258,12 @@ uint32_t default_slots(const idist_index* ix) {
     return (uint32_t)std::max<size_t>(s, 1);
 }
 
+// A/B knob for measurements: IDIST_BLOOM=0 disables the LDS Bloom filter in front of the visited bytes
+bool use_bloom_filter() {
+    const char* e = getenv("IDIST_BLOOM");
+    return !(e && e[0] == '0');
+}
+
 idist_status device_status_to_code(uint32_t st) {
     if (st & kStBadRow) return fail(IDIST_ERR_BAD_GRAPH, "device met an adjacency id >= n");
     if (st & kStTieOverflow)
@@ -355,6 +361,7 @@ idist_status run_build(idist_index* ix) {
     a.wcap = wcap;
     a.keep_pruned = cfg.keep_pruned ? 1u : 0u;
     a.has_heuristic = cfg.has_heuristic ? 1u : 0u;
+    a.use_bloom = use_bloom_filter() ? 1u : 0u;
     a.visited = d_vis;
     a.vis_stride = vis_stride;
     a.gen = d_gen;
@@ -497,6 +504,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     a.gen = ctx->d_gen;
     a.next = ctx->d_next;
     a.status = ctx->d_next + 1;
+    a.use_bloom = use_bloom_filter() ? 1u : 0u;
     const size_t smem = smem_bytes(ix->L.stride, a.wcap, false);
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_search need %zu B of LDS per wave (> 64 KiB)", smem);
     const uint32_t grid = std::min(nq, ctx->slots);

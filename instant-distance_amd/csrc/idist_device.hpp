@@ -317,20 +317,57 @@ __device__ __forceinline__ uint32_t dlog_find(const uint64_t* T, uint32_t pid) {
 // ---------------------------------------------------------------------------
 // Visited (core/types.rs:13-59) in HBM: one byte per point, per slot.
 // ---------------------------------------------------------------------------
+// In front of it an optional per-wave Bloom filter in LDS (kBloomWords x 32 bits, two hashes): it has no
+// false negatives, so "not in the filter" proves the node was not visited and the HBM byte need not be
+// read — true for ~97 % of the new nodes at ef = 100, i.e. ~3/4 of all visited reads disappear.  A "maybe"
+// falls through to the byte array, which stays the ground truth (writes always happen).
+constexpr int kBloomWords = 2048;   // 8 KB
 struct Visited {
     uint8_t* store;
     uint32_t n;
-    uint32_t gen;   // 1..255
+    uint32_t gen;       // 1..255
+    uint32_t* bloom;    // LDS, kBloomWords, or nullptr
 };
+__device__ __forceinline__ uint32_t bloom_h1(uint32_t pid) { return (pid * 0x9E3779B1u) >> 16; }
+__device__ __forceinline__ uint32_t bloom_h2(uint32_t pid) { return (pid * 0x85EBCA6Bu + 0xC2B2AE35u) >> 16; }
+__device__ __forceinline__ bool bloom_maybe(const Visited& v, uint32_t pid) {
+    const uint32_t a = bloom_h1(pid), b = bloom_h2(pid);
+    return ((v.bloom[a >> 5] >> (a & 31u)) & (v.bloom[b >> 5] >> (b & 31u)) & 1u) != 0u;
+}
+__device__ __forceinline__ void bloom_set(const Visited& v, uint32_t pid) {
+    const uint32_t a = bloom_h1(pid), b = bloom_h2(pid);
+    atomicOr(&v.bloom[a >> 5], 1u << (a & 31u));
+    atomicOr(&v.bloom[b >> 5], 1u << (b & 31u));
+}
 __device__ __forceinline__ void visited_clear(Visited& v) {  // core/types.rs:48-58
-    if (v.gen < 255u) { v.gen += 1u; return; }
     const int lane = lane_id();
+    if (v.bloom) {
+        uint4* b = reinterpret_cast<uint4*>(v.bloom);
+        for (int i = lane; i < kBloomWords / 4; i += 64) b[i] = make_uint4(0, 0, 0, 0);
+        wave_sync();
+    }
+    if (v.gen < 255u) { v.gen += 1u; return; }
     uint4* p = reinterpret_cast<uint4*>(v.store);
     const size_t n16 = ((size_t)v.n + 15u) / 16u;   // store is padded to 16 B
     for (size_t i = lane; i < n16; i += 64) p[i] = make_uint4(0, 0, 0, 0);
     __threadfence_block();
     wave_sync();
     v.gen = 1u;
+}
+// Visited::insert for one lane's pid (core/types.rs:32-40): true if it was new
+__device__ __forceinline__ bool visited_insert(const Visited& v, uint32_t pid) {
+    bool fresh = true;
+    if (!v.bloom || bloom_maybe(v, pid)) fresh = v.store[pid] != (uint8_t)v.gen;
+    if (fresh) {
+        v.store[pid] = (uint8_t)v.gen;
+        if (v.bloom) bloom_set(v, pid);
+    }
+    return fresh;
+}
+// Visited::extend with one pid per lane (core/types.rs:42-46), used by cull
+__device__ __forceinline__ void visited_mark(const Visited& v, uint32_t pid) {
+    v.store[pid] = (uint8_t)v.gen;
+    if (v.bloom) bloom_set(v, pid);
 }
 
 struct Counters { uint32_t n_dist, n_exp0, n_expU; };
@@ -340,7 +377,7 @@ template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, WState& st, Visited& vis,
                                            uint32_t* act_pid, uint32_t* act_dist, Counters& ctr, uint64_t* dlog = nullptr) {
     const int lane = lane_id();
-    if (lane == 0) { act_pid[0] = 0u; vis.store[0] = (uint8_t)vis.gen; }
+    if (lane == 0) { act_pid[0] = 0u; visited_mark(vis, 0u); }
     wave_sync();
     dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, 1);
     wave_sync();
@@ -383,12 +420,8 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
         bool fresh = false;
         if (is_nb) {
-            if (nb_pid >= ix.n) {
-                st.status |= kStBadRow;
-            } else if (vis.store[nb_pid] != (uint8_t)vis.gen) {
-                vis.store[nb_pid] = (uint8_t)vis.gen;
-                fresh = true;
-            }
+            if (nb_pid >= ix.n) st.status |= kStBadRow;
+            else fresh = visited_insert(vis, nb_pid);
         }
         const uint64_t fm = __ballot(fresh);
         const int na = __popcll(fm);

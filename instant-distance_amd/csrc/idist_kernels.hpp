@@ -63,9 +63,10 @@ struct Smem {
     uint64_t* aux;       // 3*64+1 u64 (build only): news / sel / disc
     uint32_t* act_pid;   // 64
     uint32_t* act_dist;  // 64
+    uint32_t* bloom;     // kBloomWords (graph walks only)
 };
 __host__ __device__ inline size_t smem_bytes(uint32_t stride, uint32_t wcap, bool build) {
-    size_t b = (size_t)stride * 4 * (build ? 2 : 1) + (size_t)wcap * 8 + 2 * 64 * 4;
+    size_t b = (size_t)stride * 4 * (build ? 2 : 1) + (size_t)wcap * 8 + 2 * 64 * 4 + (size_t)kBloomWords * 4;
     if (build) b += (size_t)(3 * 64 + 8) * 8;
     return b;
 }
@@ -81,6 +82,7 @@ __device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t w
     if (build) base += (size_t)(3 * 64 + 8) * 8;
     s.act_pid = reinterpret_cast<uint32_t*>(base);
     s.act_dist = s.act_pid + 64;
+    s.bloom = s.act_dist + 64;
     return s;
 }
 
@@ -99,6 +101,7 @@ struct SearchArgs {
     uint8_t* gen;           // [slots]
     uint32_t* next;         // work queue head
     uint32_t* status;
+    uint32_t use_bloom;     // LDS Bloom filter in front of the visited bytes
 };
 
 template <int NB, int RS, int TAIL>
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) 
     const Smem sm = carve(smem_raw, ix.stride, a.wcap, false);
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
-    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot]};
+    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot], a.use_bloom ? sm.bloom : nullptr};
     uint32_t status = 0;
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
     for (;;) {
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) 
             search_layer<NB, RS, TAIL>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false);
             w_cull(st);                                                // :377-379
             visited_clear(vis);
-            for (int i = lane; i < st.plen; i += 64) vis.store[(uint32_t)st.W[i]] = (uint8_t)vis.gen;
+            for (int i = lane; i < st.plen; i += 64) visited_mark(vis, (uint32_t)st.W[i]);
             wave_sync();
         }
         const int cnt = st.plen < st.ef ? st.plen : st.ef;             // search.iter(), :382
@@ -270,6 +273,7 @@ struct BuildArgs {
     uint32_t layer, top;        // LayerId of this range / of the top layer
     uint32_t efc, wcap;
     uint32_t keep_pruned;
+    uint32_t use_bloom;         // LDS Bloom filter in front of the visited bytes (descent)
     uint32_t has_heuristic;     // 0 = Builder::select_heuristic(None): select_simple + sorted splice
     uint8_t* visited;           // [slots][vis_stride]
     size_t vis_stride;
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
     uint64_t* sel = sm.aux + 64 + 8;
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
-    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot]};
+    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot], a.use_bloom ? sm.bloom : nullptr};
     uint32_t status = 0;
     Counters tot{0, 0, 0};
     for (;;) {
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
                 search_layer<NB, RS, TAIL>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dlog);
                 w_cull(st);
                 visited_clear(vis);
-                for (int i = lane; i < st.plen; i += 64) vis.store[(uint32_t)st.W[i]] = (uint8_t)vis.gen;
+                for (int i = lane; i < st.plen; i += 64) visited_mark(vis, (uint32_t)st.W[i]);
                 wave_sync();
             } else {                                                  // :458-461
                 search_layer<NB, RS, TAIL>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dlog);
