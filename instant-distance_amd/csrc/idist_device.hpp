@@ -321,7 +321,10 @@ __device__ __forceinline__ uint32_t dlog_find(const uint64_t* T, uint32_t pid) {
 // false negatives, so "not in the filter" proves the node was not visited and the HBM byte need not be
 // read — true for ~97 % of the new nodes at ef = 100, i.e. ~3/4 of all visited reads disappear.  A "maybe"
 // falls through to the byte array, which stays the ground truth (writes always happen).
-constexpr int kBloomWords = 2048;   // 8 KB
+#ifndef IDIST_BLOOM_WORDS
+#define IDIST_BLOOM_WORDS 2048
+#endif
+constexpr int kBloomWords = IDIST_BLOOM_WORDS;   // 8 KB
 struct Visited {
     uint8_t* store;
     uint32_t n;
