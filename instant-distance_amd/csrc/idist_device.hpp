@@ -321,18 +321,19 @@ __device__ __forceinline__ uint32_t dlog_find(const uint64_t* T, uint32_t pid) {
 // false negatives, so "not in the filter" proves the node was not visited and the HBM byte need not be
 // read — true for ~97 % of the new nodes at ef = 100, i.e. ~3/4 of all visited reads disappear.  A "maybe"
 // falls through to the byte array, which stays the ground truth (writes always happen).
-#ifndef IDIST_BLOOM_WORDS
-#define IDIST_BLOOM_WORDS 2048
+#ifndef IDIST_BLOOM_LOG2_WORDS
+#define IDIST_BLOOM_LOG2_WORDS 11
 #endif
-constexpr int kBloomWords = IDIST_BLOOM_WORDS;   // 8 KB
+constexpr int kBloomLog2Bits = IDIST_BLOOM_LOG2_WORDS + 5;   // 2^16 bits
+constexpr int kBloomWords = 1 << IDIST_BLOOM_LOG2_WORDS;    // 2048 words = 8 KB
 struct Visited {
     uint8_t* store;
     uint32_t n;
     uint32_t gen;       // 1..255
     uint32_t* bloom;    // LDS, kBloomWords, or nullptr
 };
-__device__ __forceinline__ uint32_t bloom_h1(uint32_t pid) { return (pid * 0x9E3779B1u) >> 16; }
-__device__ __forceinline__ uint32_t bloom_h2(uint32_t pid) { return (pid * 0x85EBCA6Bu + 0xC2B2AE35u) >> 16; }
+__device__ __forceinline__ uint32_t bloom_h1(uint32_t pid) { return (pid * 0x9E3779B1u) >> (32 - kBloomLog2Bits); }
+__device__ __forceinline__ uint32_t bloom_h2(uint32_t pid) { return (pid * 0x85EBCA6Bu + 0xC2B2AE35u) >> (32 - kBloomLog2Bits); }
 __device__ __forceinline__ bool bloom_maybe(const Visited& v, uint32_t pid) {
     const uint32_t a = bloom_h1(pid), b = bloom_h2(pid);
     return ((v.bloom[a >> 5] >> (a & 31u)) & (v.bloom[b >> 5] >> (b & 31u)) & 1u) != 0u;

@@ -15,9 +15,9 @@ here = os.path.dirname(_capi.LIB_PATH)
 flags = ("--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "
          "-fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-value -Wno-unused-result")
 libs = {}
-for words in (1024, 4096):
+for words, lg in ((1024, 10), (4096, 12)):
     out = os.path.join("/tmp", f"libidist_bloom{words}.so")
-    subprocess.check_call(f"/opt/rocm/bin/hipcc {flags} -DIDIST_BLOOM_WORDS={words} -shared -o {out} {here}/idist_capi.hip", shell=True)
+    subprocess.check_call(f"/opt/rocm/bin/hipcc {flags} -DIDIST_BLOOM_LOG2_WORDS={lg} -shared -o {out} {here}/idist_capi.hip", shell=True)
     libs[words] = out
 libs[2048] = _capi.LIB_PATH
 n, dim = 1_000_000, 300
