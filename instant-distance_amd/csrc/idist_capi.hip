@@ -258,6 +258,13 @@ uint32_t default_slots(const idist_index* ix) {
     return (uint32_t)std::max<size_t>(s, 1);
 }
 
+// Batches up to this many queries run the latency variant of the search kernel (IDIST_LATENCY_NQ overrides;
+// 0 = never).  Above it the chip is full and the leaner throughput variant wins.
+uint32_t latency_nq() {
+    if (const char* e = getenv("IDIST_LATENCY_NQ")) return (uint32_t)strtoul(e, nullptr, 10);
+    return 1024u;
+}
+
 // A/B knob for measurements: IDIST_BLOOM=0 disables the LDS Bloom filter in front of the visited bytes
 bool use_bloom_filter() {
     const char* e = getenv("IDIST_BLOOM");
@@ -286,6 +293,9 @@ idist_status run_build(idist_index* ix) {
     const uint32_t wcap = cfg.ef_construction + 64 + kTieCap + 64;
     const size_t smem = smem_bytes(ix->L.stride, wcap, true);
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave (> 64 KiB)", smem);
+    // steps too narrow to fill the chip (the early graph, max_batch = 1) run the latency variant of the descent
+    const size_t smem_lat = smem_bytes(ix->L.stride, wcap, true, kBloomLatWords);
+    const uint32_t lat_nq = smem_lat <= 64 * 1024 ? latency_nq() : 0u;
 
     // step B tile: as many selected rows on chip as fit 64 KiB of LDS next to 8 staging slots
     uint32_t rt = 8;
@@ -417,12 +427,14 @@ idist_status run_build(idist_index* ix) {
             a.efc = cfg.ef_construction;
 #define LAUNCH_BUILD(NB_, RS_, TAIL_)                                                              \
     {                                                                                              \
-        auto kA = build_insert_kernel<NB_, RS_, TAIL_>;                                            \
+        auto kA = build_insert_kernel<NB_, RS_, TAIL_, 0>;                                         \
+        auto kAl = build_insert_kernel<NB_, RS_, TAIL_, 1>;                                        \
         auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
         auto kA2 = build_select_kernel<NB_, RS_, TAIL_>;                                           \
-        IDIST_LAUNCH(kA, gridA, 64, smem, stream, view, a);                                        \
+        if (B <= lat_nq) { IDIST_LAUNCH(kAl, gridA, 64, smem_lat, stream, view, a); }              \
+        else { IDIST_LAUNCH(kA, gridA, 64, smem, stream, view, a); }                               \
         if (cfg.has_heuristic) {                                                                   \
             IDIST_LAUNCH(kA2, gridA2, 64, smemA2, stream, view, a);                                \
             IDIST_LAUNCH(kF, gridB, 64, smemF, stream, view, af);                                  \
@@ -505,17 +517,24 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     a.next = ctx->d_next;
     a.status = ctx->d_next + 1;
     a.use_bloom = use_bloom_filter() ? 1u : 0u;
-    const size_t smem = smem_bytes(ix->L.stride, a.wcap, false);
+    // narrow batches cannot fill the chip: run the latency variant (same results, overlapped round trips)
+    const bool lat = nq <= latency_nq() && smem_bytes(ix->L.stride, a.wcap, false, kBloomLatWords) <= 64 * 1024;
+    const size_t smem = smem_bytes(ix->L.stride, a.wcap, false, lat ? kBloomLatWords : kBloomWords);
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_search need %zu B of LDS per wave (> 64 KiB)", smem);
     const uint32_t grid = std::min(nq, ctx->slots);
     IndexView view = ix->view();
     HIPCHK(hipMemsetAsync(ctx->d_next, 0, 4, stream));
     const uint32_t slot = (uint32_t)(ctx->n_launch % IDIST_EVENT_RING);
     HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
-#define LAUNCH_SEARCH(NB_, RS_, TAIL_)                      \
-    {                                                       \
-        auto kS = search_kernel<NB_, RS_, TAIL_>;           \
-        IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);  \
+#define LAUNCH_SEARCH(NB_, RS_, TAIL_)                          \
+    {                                                           \
+        if (lat) {                                              \
+            auto kS = search_kernel<NB_, RS_, TAIL_, 1>;        \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);  \
+        } else {                                                \
+            auto kS = search_kernel<NB_, RS_, TAIL_, 0>;        \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);  \
+        }                                                       \
     }
     IDIST_DISPATCH(ix->L, LAUNCH_SEARCH);
 #undef LAUNCH_SEARCH

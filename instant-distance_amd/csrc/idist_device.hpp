@@ -106,6 +106,95 @@ __device__ __forceinline__ VecView natural_view(const float* q, int nb) { return
 // blocked vector q.  Result bits -> act_dist[0..na).  Group g = lane>>3 takes
 // row base+g, lane j = lane&7 runs chain j.  NB/RS/TAIL < 0 => runtime values.
 // ---------------------------------------------------------------------------
+// Cross-lane moves of the fold as DPP modifiers (VALU, no LDS crossbar round trip like ds_bpermute):
+// CTRL 0x104 = row_shl:4 (lane i reads lane i+4 of its row of 16), 0x4E = quad_perm [2,3,0,1], 0xB1 = [1,0,3,2].
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+
+// Fold of one row's 8 chains, held by the 8 lanes j = 0..7 of a group; the result is valid in lane j == 0:
+// acc_4x = lo128 + hi128 (lanes 0-3), the 4-wide tail, (s0+s2)+(s1+s3) — py/lib.rs:398-411
+__device__ __forceinline__ float fold_chains(float acc, bool has_tail, float tq, float tp) {
+    float a4 = acc + dpp_move<0x104>(acc);        // lane j<4: chain j + chain j+4
+    if (has_tail) {                               // :402-405
+        const float d = tq - tp;
+        a4 = __builtin_fmaf(d, d, a4);
+    }
+    const float s = a4 + dpp_move<0x4E>(a4);      // movehl+add, :407-408: lane 0 = s0+s2, lane 1 = s1+s3
+    return s + dpp_move<0xB1>(s);                 // add_ss, :409-411
+}
+
+// Latency variant: RIF rounds (8 rows each) are requested before the first one is consumed, so a pass costs
+// one HBM round trip per 8*RIF rows instead of one per 8 rows, and the query fragment of the lane sits in
+// registers (there is one wave per SIMD in this mode, so nothing else would hide the LDS reads).  Same
+// arithmetic, same results.
+template <int NB, int RS, int TAIL, int RIF>
+__device__ __forceinline__ void dist_rounds_inflight(const IndexView& ix, const VecView qv, const uint32_t* act_pid,
+                                                     uint32_t* act_dist, int na) {
+    static_assert(NB >= 0 && RS >= 0 && TAIL >= 0 && RIF >= 1, "compile-time layout only");
+    const int lane = lane_id();
+    const int g = lane >> 3, j = lane & 7;
+    constexpr int NBA = NB > 0 ? NB : 1, RSA = RS > 0 ? RS : 1;
+    constexpr bool QREG = NB <= 12;
+    float4 qf[QREG ? NBA : 1];
+    float qr[RSA];
+    if constexpr (QREG) {
+#pragma unroll
+        for (int u = 0; u < NB; u++) qf[u] = *reinterpret_cast<const float4*>(qv.blk + u * qv.bstride + j * 4);
+    }
+#pragma unroll
+    for (int c = 0; c < RS; c++) qr[c] = qv.rem[c * 8 + j];
+    const float qt = TAIL ? qv.rem[RS * 8 + (j & 3)] : 0.0f;
+    for (int base = 0; base < na; base += 8 * RIF) {
+        float4 p[RIF][NBA];
+        float pr[RIF][RSA], pt[RIF];
+#pragma unroll
+        for (int r = 0; r < RIF; r++) {
+            const int k = base + 8 * r + g;
+            pt[r] = 0.0f;
+            if (k < na) {
+                const float* row = ix.points + (size_t)act_pid[k] * ix.stride;
+#pragma unroll
+                for (int u = 0; u < NB; u++) p[r][u] = ldg_row4(row + u * 32 + j * 4);
+#pragma unroll
+                for (int c = 0; c < RS; c++) pr[r][c] = row[NB * 32 + c * 8 + j];
+                if (TAIL) pt[r] = row[NB * 32 + RS * 8 + (j & 3)];
+            }
+        }
+        float acc[RIF];
+#pragma unroll
+        for (int r = 0; r < RIF; r++) {
+            acc[r] = 0.0f;
+            if (base + 8 * r + g < na) {
+#pragma unroll
+                for (int u = 0; u < NB; u++) {
+                    float4 w;
+                    if constexpr (QREG) w = qf[u];
+                    else w = *reinterpret_cast<const float4*>(qv.blk + u * qv.bstride + j * 4);
+                    float d;
+                    d = w.x - p[r][u].x; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                    d = w.y - p[r][u].y; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                    d = w.z - p[r][u].z; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                    d = w.w - p[r][u].w; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                }
+#pragma unroll
+                for (int c = 0; c < RS; c++) {
+                    const float d = qr[c] - pr[r][c];
+                    acc[r] = __builtin_fmaf(d, d, acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RIF; r++) {
+            const int k = base + 8 * r + g;
+            const bool on = k < na;
+            const float res = fold_chains(acc[r], TAIL && on, qt, pt[r]);
+            if (on && j == 0) act_dist[k] = canon_bits(res, ix.metric);
+        }
+    }
+}
+
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q, const uint32_t* act_pid,
                                             uint32_t* act_dist, int na);
@@ -160,14 +249,12 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const VecView q
                 acc = __builtin_fmaf(d, d, acc);
             }
         }
-        // acc_4x = hi128 + lo128, py/lib.rs:398-400 (lanes j and j^4 hold the same sum)
-        float a4 = acc + __shfl_xor(acc, 4, 64);
+        float tq = 0.0f, tp = 0.0f;
         if (tail && on) {                    // 4-wide tail, py/lib.rs:402-405
-            const float d = qv.rem[rs * 8 + (j & 3)] - row[nb * 32 + rs * 8 + (j & 3)];
-            a4 = __builtin_fmaf(d, d, a4);
+            tq = qv.rem[rs * 8 + (j & 3)];
+            tp = row[nb * 32 + rs * 8 + (j & 3)];
         }
-        const float s = a4 + __shfl_xor(a4, 2, 64);   // (s0+s2),(s1+s3): movehl+add, :407-408
-        const float r = s + __shfl_xor(s, 1, 64);     // add_ss, :409-411
+        const float r = fold_chains(acc, tail && on, tq, tp);
         if (on && j == 0) act_dist[k] = canon_bits(r, ix.metric);
     }
 }
@@ -175,6 +262,19 @@ template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q, const uint32_t* act_pid,
                                             uint32_t* act_dist, int na) {
     dist_rounds<NB, RS, TAIL>(ix, natural_view(q, NB >= 0 ? NB : (int)ix.nb), act_pid, act_dist, na);
+}
+
+// rounds in flight of the latency variant: bounded by the VGPRs one row fragment needs (a 300-d fragment is
+// 38 dwords per lane; 8 rounds = a full 64-neighbour expansion in one HBM round trip at one wave per SIMD)
+#ifndef IDIST_RIF9
+#define IDIST_RIF9 4
+#endif
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ void dist_rounds_lat(const IndexView& ix, const float* q, const uint32_t* act_pid,
+                                                uint32_t* act_dist, int na) {
+    constexpr int RIF = NB < 0 ? 1 : (NB <= 4 ? 8 : (NB <= 12 ? IDIST_RIF9 : (NB <= 24 ? 2 : 1)));
+    if constexpr (RIF > 1) dist_rounds_inflight<NB, RS, TAIL, RIF>(ix, natural_view(q, NB), act_pid, act_dist, na);
+    else dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);
 }
 
 // ---------------------------------------------------------------------------
@@ -324,22 +424,25 @@ __device__ __forceinline__ uint32_t dlog_find(const uint64_t* T, uint32_t pid) {
 #ifndef IDIST_BLOOM_LOG2_WORDS
 #define IDIST_BLOOM_LOG2_WORDS 11
 #endif
-constexpr int kBloomLog2Bits = IDIST_BLOOM_LOG2_WORDS + 5;   // 2^16 bits
-constexpr int kBloomWords = 1 << IDIST_BLOOM_LOG2_WORDS;    // 2048 words = 8 KB
+constexpr int kBloomLog2Words = IDIST_BLOOM_LOG2_WORDS;     // 2048 words = 8 KB: throughput mode (many waves per CU)
+constexpr int kBloomWords = 1 << kBloomLog2Words;
+constexpr int kBloomLatLog2Words = 13;                      // 8192 words = 32 KB: latency mode (few waves, LDS to spare)
+constexpr int kBloomLatWords = 1 << kBloomLatLog2Words;
 struct Visited {
     uint8_t* store;
     uint32_t n;
     uint32_t gen;       // 1..255
-    uint32_t* bloom;    // LDS, kBloomWords, or nullptr
+    uint32_t* bloom;    // LDS, 1 << blog2 words, or nullptr
+    int blog2;          // log2(words)
 };
-__device__ __forceinline__ uint32_t bloom_h1(uint32_t pid) { return (pid * 0x9E3779B1u) >> (32 - kBloomLog2Bits); }
-__device__ __forceinline__ uint32_t bloom_h2(uint32_t pid) { return (pid * 0x85EBCA6Bu + 0xC2B2AE35u) >> (32 - kBloomLog2Bits); }
+__device__ __forceinline__ uint32_t bloom_h1(const Visited& v, uint32_t pid) { return (pid * 0x9E3779B1u) >> (27 - v.blog2); }
+__device__ __forceinline__ uint32_t bloom_h2(const Visited& v, uint32_t pid) { return (pid * 0x85EBCA6Bu + 0xC2B2AE35u) >> (27 - v.blog2); }
 __device__ __forceinline__ bool bloom_maybe(const Visited& v, uint32_t pid) {
-    const uint32_t a = bloom_h1(pid), b = bloom_h2(pid);
+    const uint32_t a = bloom_h1(v, pid), b = bloom_h2(v, pid);
     return ((v.bloom[a >> 5] >> (a & 31u)) & (v.bloom[b >> 5] >> (b & 31u)) & 1u) != 0u;
 }
 __device__ __forceinline__ void bloom_set(const Visited& v, uint32_t pid) {
-    const uint32_t a = bloom_h1(pid), b = bloom_h2(pid);
+    const uint32_t a = bloom_h1(v, pid), b = bloom_h2(v, pid);
     atomicOr(&v.bloom[a >> 5], 1u << (a & 31u));
     atomicOr(&v.bloom[b >> 5], 1u << (b & 31u));
 }
@@ -347,7 +450,7 @@ __device__ __forceinline__ void visited_clear(Visited& v) {  // core/types.rs:48
     const int lane = lane_id();
     if (v.bloom) {
         uint4* b = reinterpret_cast<uint4*>(v.bloom);
-        for (int i = lane; i < kBloomWords / 4; i += 64) b[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < (1 << v.blog2) / 4; i += 64) b[i] = make_uint4(0, 0, 0, 0);
         wave_sync();
     }
     if (v.gen < 255u) { v.gen += 1u; return; }
@@ -399,12 +502,47 @@ __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, 
 // Search::search (core/lib.rs:598-614) on one layer.  rows/row_stride: the
 // adjacency array (UpperNode: 32, ZeroNode: 64); links: `.take(links)`.
 // ---------------------------------------------------------------------------
-template <int NB, int RS, int TAIL>
+// first un-expanded entry after index `after`, -1 if none (does not move the cursor)
+__device__ __forceinline__ int w_peek_next(const WState& st, int after) {
+    const int lane = lane_id();
+    for (int i0 = after + 1; i0 < st.plen; i0 += 64) {
+        const int i = i0 + lane;
+        const uint64_t m = __ballot(i < st.plen && !(st.W[i] & kFlag));
+        if (m) return i0 + __builtin_ctzll(m);
+    }
+    return -1;
+}
+
+// The insertion step shared by both variants: lanes holding a fresh neighbour (key = dist<<32|pid, kMaxKey
+// otherwise) push it in slot order, core/lib.rs:606-608 + :712-719.
+__device__ __forceinline__ void w_push_keys(WState& st, uint64_t key, bool has) {
+    // entries that cannot have rank < ef even now never will (W only improves)
+    const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
+    uint64_t pm = __ballot(has && key < thr);
+    while (pm) {
+        const int i = __builtin_ctzll(pm);
+        pm &= pm - 1ull;
+        const uint64_t k = bcast_u64(key, i);
+        const int idx = w_rank(st, k);             // :712
+        if (idx < st.ef) w_insert(st, idx, k);     // :713-719
+    }
+}
+
+// LAT = 0: throughput variant (many waves per CU hide the latencies; smallest register/LDS footprint).
+// LAT = 1: latency variant for narrow batches — the same decisions in the same order, but the dependent
+//          HBM round trips of one expansion are overlapped:
+//   * the adjacency row of the candidate most likely to be expanded next is requested one expansion ahead;
+//   * neighbours the Bloom filter proves new go straight to the distance rounds while the visited bytes of
+//     the "maybe" ones are still in flight (those that turn out new get a second, usually empty, pass);
+//   * all rounds of a pass are requested together (dist_rounds_inflight).
+template <int NB, int RS, int TAIL, int LAT = 0>
 __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t* rows, int row_stride, int links,
                                              const float* q, WState& st, Visited& vis, uint32_t* act_pid,
                                              uint32_t* act_dist, Counters& ctr, bool is_zero, uint64_t* dlog = nullptr) {
     const int lane = lane_id();
     uint32_t guard = 0;
+    const bool row_lane = lane < row_stride && lane < links;
+    uint32_t pf_pid = kInvalid, pf_row = kInvalid;   // LAT: adjacency requested ahead
     for (;;) {
         const int ci = w_pop(st);                         // :599-604
         if (ci < 0) break;
@@ -416,38 +554,82 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
 
         // layer.nearest_iter(pid).take(links): stop at first INVALID (core/types.rs:183-187)
         uint32_t nb_pid = kInvalid;
-        if (lane < row_stride && lane < links) nb_pid = rows[(size_t)cpid * row_stride + lane];
+        if constexpr (LAT) {
+            if (cpid == pf_pid) nb_pid = pf_row;
+            else if (row_lane) nb_pid = rows[(size_t)cpid * row_stride + lane];
+            const int c2 = w_peek_next(st, ci);
+            pf_pid = c2 >= 0 ? (uint32_t)st.W[c2] : kInvalid;
+            pf_row = kInvalid;
+            if (pf_pid != kInvalid && row_lane) pf_row = rows[(size_t)pf_pid * row_stride + lane];
+        } else {
+            if (row_lane) nb_pid = rows[(size_t)cpid * row_stride + lane];
+        }
         const uint64_t inval = __ballot(nb_pid == kInvalid);
         const int nvalid = inval ? __builtin_ctzll(inval) : 64;
         const bool is_nb = lane < nvalid;
 
-        // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
-        bool fresh = false;
-        if (is_nb) {
-            if (nb_pid >= ix.n) st.status |= kStBadRow;
-            else fresh = visited_insert(vis, nb_pid);
-        }
-        const uint64_t fm = __ballot(fresh);
-        const int na = __popcll(fm);
-        wave_sync();
-        if (na) {
-            if (fresh) act_pid[__popcll(fm & ((1ull << lane) - 1ull))] = nb_pid;   // keeps slot order
+        if constexpr (!LAT) {
+            // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
+            bool fresh = false;
+            if (is_nb) {
+                if (nb_pid >= ix.n) st.status |= kStBadRow;
+                else fresh = visited_insert(vis, nb_pid);
+            }
+            const uint64_t fm = __ballot(fresh);
+            const int na = __popcll(fm);
             wave_sync();
-            dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);               // :709-710
+            if (na) {
+                const int my = __popcll(fm & ((1ull << lane) - 1ull));
+                if (fresh) act_pid[my] = nb_pid;                                        // keeps slot order
+                wave_sync();
+                dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);               // :709-710
+                wave_sync();
+                ctr.n_dist += (uint32_t)na;
+                uint64_t key = kMaxKey;
+                if (fresh) key = ((uint64_t)act_dist[my] << 32) | nb_pid;
+                if (dlog && fresh) dlog_insert(dlog, key);
+                w_push_keys(st, key, fresh);
+            }
+        } else {
+            bool sure = false, maybe = false;
+            uint8_t vb = 0;
+            if (is_nb) {
+                if (nb_pid >= ix.n) st.status |= kStBadRow;
+                else if (vis.bloom && !bloom_maybe(vis, nb_pid)) sure = true;
+                else { maybe = true; vb = vis.store[nb_pid]; }       // in flight during the first pass
+            }
+            if (sure) visited_mark(vis, nb_pid);
+            uint32_t my_d = 0;
+            const uint64_t sm = __ballot(sure);
             wave_sync();
-            ctr.n_dist += (uint32_t)na;
-            uint64_t key = kMaxKey;
-            if (lane < na) key = ((uint64_t)act_dist[lane] << 32) | act_pid[lane];
-            if (dlog && lane < na) dlog_insert(dlog, key);
-            // entries that cannot have rank < ef even now never will (W only improves)
-            const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
-            uint64_t pm = __ballot(lane < na && key < thr);
-            while (pm) {                                   // slot order, :606-608
-                const int i = __builtin_ctzll(pm);
-                pm &= pm - 1ull;
-                const uint64_t k = bcast_u64(key, i);
-                const int idx = w_rank(st, k);             // :712
-                if (idx < st.ef) w_insert(st, idx, k);     // :713-719
+            if (sm) {
+                const int my = __popcll(sm & ((1ull << lane) - 1ull));
+                if (sure) act_pid[my] = nb_pid;
+                wave_sync();
+                dist_rounds_lat<NB, RS, TAIL>(ix, q, act_pid, act_dist, __popcll(sm));
+                wave_sync();
+                if (sure) my_d = act_dist[my];
+            }
+            const bool late = maybe && vb != (uint8_t)vis.gen;
+            if (late) visited_mark(vis, nb_pid);
+            const uint64_t lm = __ballot(late);
+            wave_sync();
+            if (lm) {
+                const int my = __popcll(lm & ((1ull << lane) - 1ull));
+                if (late) act_pid[my] = nb_pid;
+                wave_sync();
+                dist_rounds_lat<NB, RS, TAIL>(ix, q, act_pid, act_dist, __popcll(lm));
+                wave_sync();
+                if (late) my_d = act_dist[my];
+            }
+            const bool fresh = sure || late;
+            const int na = __popcll(sm) + __popcll(lm);
+            if (na) {
+                ctr.n_dist += (uint32_t)na;
+                uint64_t key = kMaxKey;
+                if (fresh) key = ((uint64_t)my_d << 32) | nb_pid;
+                if (dlog && fresh) dlog_insert(dlog, key);
+                w_push_keys(st, key, fresh);
             }
         }
         w_truncate(st);                                    // :612
@@ -585,13 +767,7 @@ __device__ __forceinline__ uint64_t tile_any_closer(const IndexView& ix, const T
         const float d = cr[c * 8 + j] - rr[c * 8 + j];
         acc = __builtin_fmaf(d, d, acc);
     }
-    float a4 = acc + __shfl_xor(acc, 4, 64);
-    if (tail) {
-        const float d = cr[rs * 8 + (j & 3)] - rr[rs * 8 + (j & 3)];
-        a4 = __builtin_fmaf(d, d, a4);
-    }
-    const float s = a4 + __shfl_xor(a4, 2, 64);
-    const float r = s + __shfl_xor(s, 1, 64);
+    const float r = fold_chains(acc, tail != 0, tail ? cr[rs * 8 + (j & 3)] : 0.0f, tail ? rr[rs * 8 + (j & 3)] : 0.0f);
     const bool closer = on && j == 0 && canon_bits(r, ix.metric) < cd;   // strict <, core/lib.rs:678
     return __ballot(closer);   // bit 8*g set <=> R[b+g] is closer
 }

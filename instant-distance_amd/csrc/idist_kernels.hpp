@@ -63,10 +63,10 @@ struct Smem {
     uint64_t* aux;       // 3*64+1 u64 (build only): news / sel / disc
     uint32_t* act_pid;   // 64
     uint32_t* act_dist;  // 64
-    uint32_t* bloom;     // kBloomWords (graph walks only)
+    uint32_t* bloom;     // kBloomWords / kBloomLatWords, last in the carve-up (graph walks only)
 };
-__host__ __device__ inline size_t smem_bytes(uint32_t stride, uint32_t wcap, bool build) {
-    size_t b = (size_t)stride * 4 * (build ? 2 : 1) + (size_t)wcap * 8 + 2 * 64 * 4 + (size_t)kBloomWords * 4;
+__host__ __device__ inline size_t smem_bytes(uint32_t stride, uint32_t wcap, bool build, uint32_t bloom_words = kBloomWords) {
+    size_t b = (size_t)stride * 4 * (build ? 2 : 1) + (size_t)wcap * 8 + 2 * 64 * 4 + (size_t)bloom_words * 4;
     if (build) b += (size_t)(3 * 64 + 8) * 8;
     return b;
 }
@@ -104,13 +104,15 @@ struct SearchArgs {
     uint32_t use_bloom;     // LDS Bloom filter in front of the visited bytes
 };
 
-template <int NB, int RS, int TAIL>
+// LAT = 1: latency variant for narrow batches (see search_layer).
+template <int NB, int RS, int TAIL, int LAT = 0>
 __global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) {
     IDIST_DYN_SMEM(smem_raw);
     const Smem sm = carve(smem_raw, ix.stride, a.wcap, false);
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
-    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot], a.use_bloom ? sm.bloom : nullptr};
+    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot], a.use_bloom ? sm.bloom : nullptr,
+                LAT ? kBloomLatLog2Words : kBloomLog2Words};
     uint32_t status = 0;
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
     for (;;) {
@@ -134,11 +136,11 @@ __global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) 
             const bool is_zero = cur == 0;
             st.ef = is_zero ? (int)a.ef : 1;                           // :366-371
             if (is_zero) {
-                search_layer<NB, RS, TAIL>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true);
+                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true);
                 break;
             }
             const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-            search_layer<NB, RS, TAIL>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false);
+            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false);
             w_cull(st);                                                // :377-379
             visited_clear(vis);
             for (int i = lane; i < st.plen; i += 64) visited_mark(vis, (uint32_t)st.W[i]);
@@ -329,14 +331,15 @@ __device__ __forceinline__ void emit_new_node(const IndexView& ix, const BuildAr
     }
 }
 
-template <int NB, int RS, int TAIL>
+template <int NB, int RS, int TAIL, int LAT = 0>
 __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArgs a) {
     IDIST_DYN_SMEM(smem_raw);
     const Smem sm = carve(smem_raw, ix.stride, a.wcap, true);
     uint64_t* sel = sm.aux + 64 + 8;
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
-    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot], a.use_bloom ? sm.bloom : nullptr};
+    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot], a.use_bloom ? sm.bloom : nullptr,
+                LAT ? kBloomLatLog2Words : kBloomLog2Words};
     uint32_t status = 0;
     Counters tot{0, 0, 0};
     for (;;) {
@@ -361,13 +364,13 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
             st.ef = cur <= (int)a.layer ? (int)a.efc : 1;             // :448-452
             if (cur > (int)a.layer) {                                 // :453-457
                 const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-                search_layer<NB, RS, TAIL>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dlog);
+                search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dlog);
                 w_cull(st);
                 visited_clear(vis);
                 for (int i = lane; i < st.plen; i += 64) visited_mark(vis, (uint32_t)st.W[i]);
                 wave_sync();
             } else {                                                  // :458-461
-                search_layer<NB, RS, TAIL>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dlog);
+                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dlog);
                 break;
             }
         }

@@ -4,9 +4,36 @@ Every case calls the product through the C ABI (include/idist.h, via the ctypes 
 layer) and checks it against the CPU oracle on the same seeded inputs.  Bit-exact for
 ids/order/counts/counters; distances compared as raw f32 bits.
 """
+import contextlib
+import os
+
 import numpy as np
 
 INVALID = 0xFFFFFFFF
+
+# the search kernel has a throughput and a latency variant (chosen by the batch width, IDIST_LATENCY_NQ);
+# both must give the reference's results
+SEARCH_VARIANTS = (("throughput", "0"), ("latency", "4000000000"))
+
+
+@contextlib.contextmanager
+def search_variant(latency_nq):
+    old = os.environ.get("IDIST_LATENCY_NQ")
+    os.environ["IDIST_LATENCY_NQ"] = latency_nq
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("IDIST_LATENCY_NQ", None)
+        else:
+            os.environ["IDIST_LATENCY_NQ"] = old
+
+
+def check_search_result(got, want):
+    assert np.array_equal(got.count, want.count)
+    assert np.array_equal(got.pid, want.pid)
+    assert np.array_equal(bits(got.distance), bits(want.dist))
+    assert np.array_equal(got.counters, want.counters)
 
 
 def bits(a):
@@ -70,12 +97,11 @@ def check_search_parity(ida, oracle, n, dim, ef_search=100, metric=0, kind="unif
     q = gen_points(rng, nq, dim, kind)
     if kind == "uniform" and nq > 2:
         q[1] = pts[min(5, n - 1)]          # a stored point: distance 0 first (test.py:15-35)
-    got = h.search_batch(q, ida.Search(), counters=True)
     want = oix.search(q, threads=1)
-    assert np.array_equal(got.count, want.count)
-    assert np.array_equal(got.pid, want.pid)
-    assert np.array_equal(bits(got.distance), bits(want.dist))
-    assert np.array_equal(got.counters, want.counters)
+    for _, lat in SEARCH_VARIANTS:
+        with search_variant(lat):
+            got = h.search_batch(q, ida.Search(), counters=True)
+        check_search_result(got, want)
     # sortedness + idempotence (size independent properties)
     for i in range(nq):
         c = int(got.count[i])
@@ -97,15 +123,17 @@ def check_build_exact(ida, oracle, n, dim, metric=0, kind="uniform", ef_construc
     oix = oracle.Index.build(pts, cfg, threads=1)
     b = (ida.Builder().metric(metric).max_batch(1).ef_construction(ef_construction)
          .select_heuristic(ida.Heuristic(False, keep_pruned) if heuristic else None))
-    h = ida.Hnsw.from_ordered_points(pts, b)
-    zero, layers = h.into_parts()
-    assert np.array_equal(zero, oix.zero)
-    assert len(layers) == len(oix.layers)
-    for a, o in zip(layers, oix.layers):
-        assert np.array_equal(a, o)
-    st = h.build_stats()
-    assert st.n_dist == oix.build_counters.n_dist
-    assert st.n_exp0 == oix.build_counters.n_exp0 and st.n_expU == oix.build_counters.n_expU
+    for _, lat in SEARCH_VARIANTS:        # the descent of an insertion has the same two variants as the search
+        with search_variant(lat):
+            h = ida.Hnsw.from_ordered_points(pts, b)
+        zero, layers = h.into_parts()
+        assert np.array_equal(zero, oix.zero)
+        assert len(layers) == len(oix.layers)
+        for a, o in zip(layers, oix.layers):
+            assert np.array_equal(a, o)
+        st = h.build_stats()
+        assert st.n_dist == oix.build_counters.n_dist
+        assert st.n_exp0 == oix.build_counters.n_exp0 and st.n_expU == oix.build_counters.n_expU
     return h
 
 

@@ -69,6 +69,7 @@ static const char* op_name(int op) {
         case OP_SHFL: return "__shfl";
         case OP_SHFL_XOR: return "__shfl_xor";
         case OP_READFIRST: return "readfirstlane";
+        case OP_DPP: return "dpp";
         default: return "none";
     }
 }
@@ -141,6 +142,21 @@ void launch(uint32_t grid, uint32_t block, size_t smem_bytes, const std::functio
                         case OP_SHFL: { const Lane& o = s.lanes[lo + ((uint32_t)l.arg & 63u)]; l.res = (lo + ((uint32_t)l.arg & 63u) < hi && o.alive) ? o.val : 0; break; }
                         case OP_SHFL_XOR: { const uint32_t j = lo + (li ^ (uint32_t)l.arg); l.res = (j < hi && s.lanes[j].alive) ? s.lanes[j].val : l.val; break; }
                         case OP_READFIRST: l.res = s.lanes[first].val; break;
+                        case OP_DPP: {
+                            const uint32_t ctrl = (uint32_t)l.arg;
+                            int64_t src = -1;
+                            if (ctrl <= 0xFFu) src = (int64_t)((li & ~3u) + ((ctrl >> (2u * (li & 3u))) & 3u));   // quad_perm
+                            else if (ctrl >= 0x101u && ctrl <= 0x10Fu) {                                          // row_shl:n
+                                const uint32_t j = li + (ctrl & 15u);
+                                if ((j >> 4) == (li >> 4)) src = j;
+                            } else if (ctrl >= 0x111u && ctrl <= 0x11Fu) {                                        // row_shr:n
+                                const uint32_t n = ctrl & 15u;
+                                if ((li & 15u) >= n) src = li - n;
+                            } else { fprintf(stderr, "[hip_emu] dpp ctrl 0x%x not emulated\n", ctrl); abort(); }
+                            if (src < 0 || lo + (uint32_t)src >= hi || !s.lanes[lo + (uint32_t)src].alive) l.res = 1ull << 32;
+                            else l.res = (uint32_t)s.lanes[lo + (uint32_t)src].val;
+                            break;
+                        }
                         case OP_MFMA_32x32x2: {
                             const uint32_t col = li & 31u;
                             for (int r = 0; r < 16; r++) {

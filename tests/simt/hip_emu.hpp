@@ -36,7 +36,7 @@ namespace emu {
 
 struct Dim3 { uint32_t x, y, z; };
 
-enum Op { OP_NONE = 0, OP_SYNC, OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_READFIRST, OP_MFMA_32x32x2 };
+enum Op { OP_NONE = 0, OP_SYNC, OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_READFIRST, OP_MFMA_32x32x2, OP_DPP };
 
 struct Lane {
     void* sp = nullptr;          // saved stack pointer
@@ -109,6 +109,14 @@ static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) {
     return (uint32_t)::emu::collective(::emu::OP_READFIRST, v, 0);
 }
 static inline void __threadfence_block() {}
+// v_mov_b32_dpp: quad_perm (ctrl 0x00-0xFF) and row_shl:n / row_shr:n (0x101-0x10F / 0x111-0x11F), all rows and
+// banks enabled; a source lane outside the row reads 0 with bound_ctrl, keeps `old` without.
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    if (row_mask != 0xF || bank_mask != 0xF) { fprintf(stderr, "[hip_emu] dpp row/bank masks not emulated\n"); abort(); }
+    const uint64_t r = ::emu::collective(::emu::OP_DPP, (uint32_t)src, ctrl);
+    if (r >> 32) return bound_ctrl ? 0 : old;   // invalid source lane
+    return (int)(uint32_t)r;
+}
 
 // v_mfma_f32_32x32x2_f32: D = A(32x2) * B(2x32) + C, exact f32, k-ordered fma chain.
 // lane l: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]; C/D reg r: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)

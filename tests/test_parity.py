@@ -56,14 +56,15 @@ def test_search_parity_heavy_ties(eng, oracle):
     oix = oracle.Index.build(pts, cfg)
     h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().metric(1).ef_search(20))
     q = rng.integers(0, 3, size=(S(kind, 8, 200), 4)).astype(np.float32)
-    try:
-        got = h.search_batch(q, ida.Search(), counters=True)
-    except ida.IdistError as e:          # > 64 live equidistant candidates is reported, never silent
-        assert e.status == 6
-        return
     want = oix.search(q)
-    assert np.array_equal(got.pid, want.pid) and np.array_equal(got.counters, want.counters)
-    assert np.array_equal(pc.bits(got.distance), pc.bits(want.dist))
+    for _, lat in pc.SEARCH_VARIANTS:
+        try:
+            with pc.search_variant(lat):
+                got = h.search_batch(q, ida.Search(), counters=True)
+        except ida.IdistError as e:          # > 64 live equidistant candidates is reported, never silent
+            assert e.status == 6
+            continue
+        pc.check_search_result(got, want)
 
 
 def test_duplicate_points(eng, oracle):
@@ -81,9 +82,11 @@ def test_duplicate_points(eng, oracle):
     zero, layers = h.into_parts()
     assert np.array_equal(zero, oix.zero)
     q = np.concatenate([pts[: S(kind, 6, 100)], rng.random((S(kind, 4, 100), dim), dtype=np.float32)])
-    got, want = h.search_batch(q, ida.Search(), counters=True), oix.search(q)
-    assert np.array_equal(got.pid, want.pid) and np.array_equal(got.counters, want.counters)
-    assert np.array_equal(pc.bits(got.distance), pc.bits(want.dist))
+    want = oix.search(q)
+    for _, lat in pc.SEARCH_VARIANTS:
+        with pc.search_variant(lat):
+            got = h.search_batch(q, ida.Search(), counters=True)
+        pc.check_search_result(got, want)
 
 
 def test_search_on_parallel_built_graph(eng, oracle):
