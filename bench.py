@@ -231,6 +231,17 @@ def main():
                     "n_dist_per_query": round(float(ctr[:, 0].mean()), 1), "n_exp0_per_query": round(float(ctr[:, 1].mean()), 1),
                     "n_expU_per_query": round(float(ctr[:, 2].mean()), 1)}
 
+        # the reference's own call pattern: one query per call (`Hnsw::search`).  Outside the timed region.
+        lat_n = min(32, nq)
+        for i in range(lat_n):
+            hnsw.search_batch_device(search, d_q[i:i + 1].data_ptr(), 1, outs[0].data_ptr(), outs[1].data_ptr(),
+                                     outs[2].data_ptr(), outs[3].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        single = {"gpu_kernel_ms_median": round(float(np.median(search.kernel_times_ms(lat_n))), 4), "queries": lat_n,
+                  "note": "nq = 1 per launch, latency variant of the graph walk; cpu = one oracle thread"}
+        run(chosen, outs)                      # restore the full-batch outputs the checks below read
+        torch.cuda.synchronize()
+
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle import pyoracle as po
@@ -248,6 +259,8 @@ def main():
             for _ in range(3):
                 t0 = time.perf_counter(); ores = oix.search(q_h[:sample], threads=cores); tc = min(tc, time.perf_counter() - t0)
             same = bool(np.array_equal(ores.pid, outs[0][:sample].cpu().numpy().astype(np.uint32)))
+            t0 = time.perf_counter(); oix.search(q_h[:200], threads=1)
+            single["cpu_ms_per_query_one_thread"] = round((time.perf_counter() - t0) / min(200, nq) * 1e3, 4)
             # build baseline: the oracle's threaded build (per-layer parallel-for + per-node locks, the rayon path of
             # core/lib.rs:316-318) on a PREFIX of the same points — the rate falls with n, so this flatters the CPU
             nb_ = min(n, args.cpu_build_sample)
@@ -273,7 +286,7 @@ def main():
                           "recall_target_met": bool(recall >= args.recall_target), "recall_queries": gtq,
                           "ef_sweep_recall": sweep, "parallelism": f"query-shard x{world}, index replicated",
                           "replication": replication, "replicate_seconds": round(t_rep, 3)},
-               "build": build, "roofline": roofline, "cpu_baseline": cpu}
+               "build": build, "roofline": roofline, "cpu_baseline": cpu, "single_query": single}
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 2)
         print(json.dumps(out), flush=True)

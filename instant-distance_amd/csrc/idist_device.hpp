@@ -502,6 +502,12 @@ __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, 
 // Search::search (core/lib.rs:598-614) on one layer.  rows/row_stride: the
 // adjacency array (UpperNode: 32, ZeroNode: 64); links: `.take(links)`.
 // ---------------------------------------------------------------------------
+#ifndef IDIST_TP_PFA
+#define IDIST_TP_PFA 0
+#endif
+#ifndef IDIST_TP_OVL
+#define IDIST_TP_OVL 0
+#endif
 // first un-expanded entry after index `after`, -1 if none (does not move the cursor)
 __device__ __forceinline__ int w_peek_next(const WState& st, int after) {
     const int lane = lane_id();
@@ -542,7 +548,9 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     const int lane = lane_id();
     uint32_t guard = 0;
     const bool row_lane = lane < row_stride && lane < links;
-    uint32_t pf_pid = kInvalid, pf_row = kInvalid;   // LAT: adjacency requested ahead
+    constexpr bool PFA = LAT || IDIST_TP_PFA;        // adjacency requested one expansion ahead
+    constexpr bool OVL = LAT || IDIST_TP_OVL;        // visited bytes in flight during the first distance pass
+    uint32_t pf_pid = kInvalid, pf_row = kInvalid;
     for (;;) {
         const int ci = w_pop(st);                         // :599-604
         if (ci < 0) break;
@@ -554,7 +562,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
 
         // layer.nearest_iter(pid).take(links): stop at first INVALID (core/types.rs:183-187)
         uint32_t nb_pid = kInvalid;
-        if constexpr (LAT) {
+        if constexpr (PFA) {
             if (cpid == pf_pid) nb_pid = pf_row;
             else if (row_lane) nb_pid = rows[(size_t)cpid * row_stride + lane];
             const int c2 = w_peek_next(st, ci);
@@ -568,7 +576,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         const int nvalid = inval ? __builtin_ctzll(inval) : 64;
         const bool is_nb = lane < nvalid;
 
-        if constexpr (!LAT) {
+        if constexpr (!OVL) {
             // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
             bool fresh = false;
             if (is_nb) {
@@ -606,7 +614,8 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 const int my = __popcll(sm & ((1ull << lane) - 1ull));
                 if (sure) act_pid[my] = nb_pid;
                 wave_sync();
-                dist_rounds_lat<NB, RS, TAIL>(ix, q, act_pid, act_dist, __popcll(sm));
+                if constexpr (LAT) dist_rounds_lat<NB, RS, TAIL>(ix, q, act_pid, act_dist, __popcll(sm));
+                else dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, __popcll(sm));
                 wave_sync();
                 if (sure) my_d = act_dist[my];
             }
@@ -618,7 +627,8 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 const int my = __popcll(lm & ((1ull << lane) - 1ull));
                 if (late) act_pid[my] = nb_pid;
                 wave_sync();
-                dist_rounds_lat<NB, RS, TAIL>(ix, q, act_pid, act_dist, __popcll(lm));
+                if constexpr (LAT) dist_rounds_lat<NB, RS, TAIL>(ix, q, act_pid, act_dist, __popcll(lm));
+                else dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, __popcll(lm));
                 wave_sync();
                 if (late) my_d = act_dist[my];
             }
