@@ -372,3 +372,18 @@ def test_permutation_matches_oracle_restatement(eng, oracle):
         oa, ob = oracle.permutation(seed, n)
         assert np.array_equal(a, oa) and np.array_equal(b, ob)
         assert sorted(a.tolist()) == list(range(n))
+
+
+@pytest.mark.parametrize("order", ["forward", "reverse"])
+def test_emulator_lane_schedule_independence(engine_loader, oracle, monkeypatch, order):
+    """The lockstep emulator runs the lanes of a wave one after the other between collectives; results must not
+    depend on that order (a cross-lane LDS hand-off without a barrier would), and no collective may be reached
+    with lanes missing (STRICT).  Search (both variants), exact build and the heuristic=None build."""
+    ida = engine_loader("emu")
+    monkeypatch.setenv("IDIST_EMU_ORDER", order)
+    monkeypatch.setenv("IDIST_EMU_STRICT", "1")
+    pc.check_search_parity(ida, oracle, n=160, dim=12, ef_search=40, nq=3, seed=5)
+    pc.check_search_parity(ida, oracle, n=120, dim=300, ef_search=100, nq=2, seed=6)
+    pc.check_build_exact(ida, oracle, n=70, dim=6, seed=7)
+    pc.check_build_exact(ida, oracle, n=80, dim=5, seed=8, heuristic=False)
+    pc.check_build_batched(ida, oracle, n=130, dim=8, max_batch=0, nq=8, seed=9, min_recall=0.9)
