@@ -28,8 +28,8 @@
  *                          variant of the graph walk; default 1024, 0 = never
  *   IDIST_BLOOM=0          no LDS Bloom filter in front of the visited bytes
  *   IDIST_BRUTEFORCE=scan|mfma, IDIST_BF_SAMPLE=<n>   force a path of idist_bruteforce / its sample size
- *   IDIST_BUILD_RT, IDIST_BUILD_RT2, IDIST_BUILD_NO_FAST  build tile sizes / route every neighbour
- *                          update through the from-scratch kernel
+ *   IDIST_BUILD_RT, IDIST_BUILD_RT2, IDIST_BUILD_NO_FAST, IDIST_BUILD_CHUNK  build tile sizes / route every
+ *                          neighbour update through the from-scratch kernel / updates per work-queue dequeue
  */
 #ifndef IDIST_H
 #define IDIST_H

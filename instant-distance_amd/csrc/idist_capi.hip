@@ -393,6 +393,7 @@ idist_status run_build(idist_index* ix) {
     a.wbuf = d_wbuf;
     a.wcount = d_wcount;
     a.rt2 = rt2;
+    if (const char* e = getenv("IDIST_BUILD_CHUNK")) a.chunk = (uint32_t)atoi(e);
     const size_t smemF = smem_bytes_update_fast(ix->L.stride);
     const bool no_fast = getenv("IDIST_BUILD_NO_FAST") != nullptr;   // test knob: route every update through B2
     a.stats = d_stats;

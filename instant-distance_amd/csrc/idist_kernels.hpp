@@ -296,6 +296,7 @@ struct BuildArgs {
     uint32_t* wcount;           // [max_batch]
     uint32_t rt;                // step B2: selected rows kept in the LDS tile
     uint32_t rt2;               // step A2: same for the new point's own selection
+    uint32_t chunk;             // step B: items per dequeue, 0 = by load (IDIST_BUILD_CHUNK, test knob)
     uint32_t* queue;            // work queue heads: [0] step A, [1] step B, [3] step B2, [4] step A2 ([2] = n_slow)
     unsigned long long* stats;  // [8] n_dist n_exp0 n_expU n_heur_dist n_heur_rows n_updates
     uint32_t* status;
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
     HeurCounters hc{0, 0};
     uint32_t updates = 0, deferred = 0, status = 0;
     // items per dequeue: 37 M updates through one counter would cost ~0.4 s; small steps keep 1 item per wave
-    uint32_t kChunk = ntouched / (gridDim.x * 4u);
+    uint32_t kChunk = a.chunk ? a.chunk : ntouched / (gridDim.x * 4u);
     kChunk = kChunk < 1u ? 1u : (kChunk > 16u ? 16u : kChunk);
     uint32_t t_next = 0, t_end = 0;
     for (;;) {
@@ -623,7 +624,92 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
         const int total = ncur + k_new;
         bool defer = k_new > kMaxNewFast || total > (int)a.efc || guard > a.count;
         int nR = 0, nD = 0;
-        if (!defer) {
+        bool handled = false;
+        if (!defer && k_new == 1) {
+            // One new point (the common case; the only case with max_batch = 1): the replay below collapses to a
+            // few wave-wide tests, because every stored verdict in front of the new point stands, and behind it
+            //   * the new point is pruned iff a selected entry in front of it is closer to it than `pid` is;
+            //   * if it is selected instead, an old selected entry s behind it is newly pruned iff
+            //     d(new, s) < d(pid, s)   (set P), and an old discarded entry keeps its verdict unless its
+            //     stored pruner is in P — that cascade is left to the sequential replay.
+            const uint64_t knew = news[0] & kKeyMask;
+            const uint32_t new_pid = (uint32_t)knew, cd_new = (uint32_t)(knew >> 32);
+            const bool selL = lane < ns0, discL = lane >= ns0 && lane < ncur;
+            const uint64_t below = (1ull << lane) - 1ull;
+            const uint64_t* T = a.dlog + (size_t)(new_pid - a.start) * kDlogCap;
+            uint32_t dn = kDlogMiss;                         // d(new, selected entry of this lane)
+            if (selL) dn = dlog_find(T, cur);
+            const bool miss = selL && dn == kDlogMiss;
+            const uint64_t mm = __ballot(miss);
+            if (mm) {
+                const int n0 = __popcll(mm), at = __popcll(mm & below);
+                if (miss) act_p[at] = cur;
+                const float* prow = ix.points + (size_t)new_pid * ix.stride;
+                for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+                    *reinterpret_cast<float4*>(cq + o) = *reinterpret_cast<const float4*>(prow + o);
+                wave_sync();
+                dist_rounds<NB, RS, TAIL>(ix, cq, act_p, act_d, n0);
+                wave_sync();
+                if (miss) dn = act_d[at];
+                hc.n_dist += (uint32_t)n0;
+                hc.n_rows += 1;
+            }
+            const bool before = lane < ncur && key < knew;
+            const int nb = __popcll(__ballot(selL && before));           // |R| when the new point's turn comes
+            const uint64_t cm = __ballot(selL && before && dn < cd_new);   // strict <, :678
+            const int nd_old = ncur - ns0;
+            wave_sync();
+            if (nb >= kM2) {
+                // R is full before the new point is reached (:669-671): the row stands
+                if (selL) sel[lane] = key;
+                nR = ns0;
+                nD = 0;
+                handled = true;
+            } else if (cm) {
+                // pruned: it joins the discarded list at its place; R is unchanged
+                const uint32_t pr = readlane_u32(cur, __builtin_ctzll(cm));
+                const int npos = __popcll(__ballot(discL && before));
+                if (selL) sel[lane] = key;
+                if (discL) {
+                    const int dp = (lane - ns0) + (before ? 0 : 1);
+                    if (dp < kM2) { disc[dp] = key; dprn[dp] = cura; }
+                }
+                if (lane == 0 && npos < kM2) { disc[npos] = knew; dprn[npos] = pr; }
+                nR = ns0;
+                nD = nd_old + 1;
+                handled = true;
+            } else {
+                const bool inP = selL && !before && dn < curd;         // d(new, s) < d(pid, s)
+                const uint64_t P = __ballot(inP);
+                bool casc = false;
+                int dp = lane - ns0;                                   // place in the merged discarded list
+                int pi = 0;
+                for (uint64_t pm = P; pm; pm &= pm - 1ull, pi++) {
+                    const int i = __builtin_ctzll(pm);
+                    const uint32_t ppid = readlane_u32(cur, i);
+                    const uint64_t kp = bcast_u64(key, i);
+                    casc = casc || (discL && cura == ppid);
+                    const int less = __popcll(__ballot(discL && key < kp));
+                    if (discL && kp < key) dp += 1;
+                    if (lane == i) dp = pi + less;
+                }
+                if (__ballot(casc) == 0ull) {
+                    const int nP = __popcll(P);
+                    if (selL && !inP) {
+                        const int rp = lane - __popcll(P & below) + (before ? 0 : 1);
+                        if (rp < kM2) sel[rp] = key;
+                    }
+                    if (lane == 0) sel[nb] = knew;
+                    if ((discL || inP) && dp < kM2) { disc[dp] = key; dprn[dp] = inP ? new_pid : cura; }
+                    nR = ns0 - nP + 1;
+                    if (nR > kM2) nR = kM2;
+                    nD = nd_old + nP;
+                    handled = true;
+                }
+            }
+            wave_sync();
+        }
+        if (!defer && !handled) {
             // candidates = sort(current U new) — nothing can be dropped by `idx < ef` (total <= ef)
             if (lane < ncur) curk[lane] = key;
             if (lane < ns0) X[lane] = cur;

@@ -170,6 +170,31 @@ def test_build_batched(eng, oracle):
     assert rec >= 0.95
 
 
+def test_build_batched_is_schedule_independent(eng, oracle, monkeypatch):
+    """A concurrent step's outcome must not depend on how its work is scheduled on the device: the same points
+    built with different work-queue chunkings (which switches the update kernel's next-item prefetch on and
+    off), with every update forced through the from-scratch kernel, and with the latency / throughput descent
+    give byte-identical graphs."""
+    ida, kind = eng
+    rng = np.random.default_rng(4)
+    pts = pc.gen_points(rng, S(kind, 300, 60000), S(kind, 6, 48), "lowrank" if kind == "gpu" else "uniform")
+    b = ida.Builder().max_batch(S(kind, 16, 0))
+    ref = None
+    envs = [{}, {"IDIST_BUILD_CHUNK": "5"}, {"IDIST_BUILD_NO_FAST": "1"}, {"IDIST_LATENCY_NQ": "0"}]
+    if kind == "gpu":
+        envs += [{"IDIST_BUILD_CHUNK": "1"}, {"IDIST_BUILD_CHUNK": "16"}, {"IDIST_LATENCY_NQ": "4000000000"}]
+    for env in envs:
+        with monkeypatch.context() as m:
+            for k_, v in env.items():
+                m.setenv(k_, v)
+            zero, layers = ida.Hnsw.from_ordered_points(pts, b).into_parts()
+        if ref is None:
+            ref = (zero, layers)
+            continue
+        assert np.array_equal(zero, ref[0]), env
+        assert all(np.array_equal(x, y) for x, y in zip(layers, ref[1])), env
+
+
 @pytest.mark.gpu
 def test_build_batched_matches_oracle_recall_gpu(engine_loader, oracle):
     """throughput-mode tier: recall@10 within noise of the oracle's parallel build."""
