@@ -412,3 +412,37 @@ def test_emulator_lane_schedule_independence(engine_loader, oracle, monkeypatch,
     pc.check_build_exact(ida, oracle, n=70, dim=6, seed=7)
     pc.check_build_exact(ida, oracle, n=80, dim=5, seed=8, heuristic=False)
     pc.check_build_batched(ida, oracle, n=130, dim=8, max_batch=0, nq=8, seed=9, min_recall=0.9)
+
+
+@pytest.mark.gpu
+def test_index_shared_by_threads_gpu(engine_loader, oracle):
+    """`Hnsw::search(&self, …, &mut Search)` (core/lib.rs:352-356): the index is immutable and shareable, all
+    mutable state lives in the caller's `Search`.  Several host threads, each with its own Search (= its own
+    stream + scratch), query one index concurrently; every thread gets the oracle's answer.  (GPU only: the
+    CPU emulator of tests/simt is single-threaded by design.)"""
+    import threading
+
+    ida, kind = engine_loader("gpu"), "gpu"
+    pts, oix, _ = pc.oracle_graph(oracle, S(kind, 240, 20000), S(kind, 8, 96), "uniform", 0, 31, 1, 100)
+    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder())
+    rng = np.random.default_rng(32)
+    n_thr = S(kind, 3, 6)
+    qs = [pc.gen_points(rng, S(kind, 4, 300 + 700 * (i % 2)), pts.shape[1]) for i in range(n_thr)]   # narrow and wide batches
+    wants = [oix.search(q, threads=1) for q in qs]
+    errs = []
+
+    def work(i):
+        try:
+            s = ida.Search()
+            for _ in range(S(kind, 2, 5)):
+                got = h.search_batch(qs[i], s, counters=True)
+                pc.check_search_result(got, wants[i])
+        except BaseException as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(n_thr)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
