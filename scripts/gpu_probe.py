@@ -57,6 +57,10 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["c2", "mid", "c3"]
     if "c2" in which:
         stage("c2_100k_128_U", 100_000, 128, "uniform")
+    if "c2l" in which:
+        stage("c2_100k_128_L", 100_000, 128, "lowrank", efs=(100, 200))
+    if "c4" in which:
+        stage("c4_1M_768_L", 1_000_000, 768, "lowrank", nq=65536, efs=(100, 200), gt_q=2000)
     if "mid" in which:
         stage("mid_200k_300_L", 200_000, 300, "lowrank", efs=(100, 200))
     if "c3" in which:
