@@ -519,19 +519,84 @@ __device__ __forceinline__ int w_peek_next(const WState& st, int after) {
     return -1;
 }
 
-// The insertion step shared by both variants: lanes holding a fresh neighbour (key = dist<<32|pid, kMaxKey
-// otherwise) push it in slot order, core/lib.rs:606-608 + :712-719.
+// The insertion step shared by both variants: lanes holding a fresh neighbour (key = dist<<32|pid) push it in
+// slot order, core/lib.rs:606-608 + :712-719.  `push` accepts key i iff fewer than ef entries of `nearest` —
+// the list as of that moment, i.e. the old one plus the keys accepted earlier in this expansion — are smaller;
+// nothing is truncated before the expansion ends (:612).  So acceptance is decided from the rank in the old
+// list plus a count over the earlier accepted lanes, and the accepted keys are merged into W in one pass
+// instead of one shifted insertion each.
+constexpr int kPushChunks = 8;   // one-pass merge for W up to 512 entries, sequential insertion beyond
 __device__ __forceinline__ void w_push_keys(WState& st, uint64_t key, bool has) {
+    const int lane = lane_id();
     // entries that cannot have rank < ef even now never will (W only improves)
     const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
-    uint64_t pm = __ballot(has && key < thr);
-    while (pm) {
-        const int i = __builtin_ctzll(pm);
-        pm &= pm - 1ull;
-        const uint64_t k = bcast_u64(key, i);
-        const int idx = w_rank(st, k);             // :712
-        if (idx < st.ef) w_insert(st, idx, k);     // :713-719
+    const bool cand = has && key < thr;
+    uint64_t pm = __ballot(cand);
+    if (!pm) return;
+    const int plen = st.plen;
+    if (plen > 64 * kPushChunks) {
+        while (pm) {
+            const int i = __builtin_ctzll(pm);
+            pm &= pm - 1ull;
+            const uint64_t k = bcast_u64(key, i);
+            const int idx = w_rank(st, k);             // :712
+            if (idx < st.ef) w_insert(st, idx, k);     // :713-719
+        }
+        return;
     }
+    // rank in the old list (Vec::binary_search, :712)
+    int r0 = 0;
+    if (cand) {
+        int lo = 0, hi = plen;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((st.W[mid] & kKeyMask) < key) lo = mid + 1; else hi = mid;
+        }
+        r0 = lo;
+    }
+    const uint32_t k_lo = (uint32_t)key, k_hi = (uint32_t)(key >> 32);
+    bool acc = false;
+    for (uint64_t m = pm; m; m &= m - 1ull) {              // slot order
+        const int i = __builtin_ctzll(m);
+        const uint64_t ki = ((uint64_t)readlane_u32(k_hi, i) << 32) | readlane_u32(k_lo, i);
+        const int ri = (int)readlane_u32((uint32_t)r0, i);
+        const int c = __popcll(__ballot(acc && key < ki));
+        if (lane == i) acc = ri + c < st.ef;               // idx < ef, :713
+    }
+    const uint64_t A = __ballot(acc);
+    if (!A) return;
+    // merge: an old entry moves up by the number of accepted keys below it, an accepted key lands at its old
+    // rank plus the number of accepted keys below it
+    int first = plen;
+    for (uint64_t m = A; m; m &= m - 1ull) {
+        const int ri = (int)readlane_u32((uint32_t)r0, __builtin_ctzll(m));
+        first = ri < first ? ri : first;
+    }
+    const int c0 = first >> 6;
+    uint64_t w[kPushChunks];
+    int sh[kPushChunks];
+#pragma unroll
+    for (int c = 0; c < kPushChunks; c++) {
+        const int t = c * 64 + lane;
+        sh[c] = 0;
+        w[c] = (c >= c0 && t < plen) ? st.W[t] : 0ull;     // 0 never moves (no key is below it)
+    }
+    int below = 0;
+    for (uint64_t m = A; m; m &= m - 1ull) {
+        const int i = __builtin_ctzll(m);
+        const uint64_t kj = ((uint64_t)readlane_u32(k_hi, i) << 32) | readlane_u32(k_lo, i);
+        below += (acc && kj < key) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < kPushChunks; c++) sh[c] += (w[c] & kKeyMask) > kj ? 1 : 0;
+    }
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < kPushChunks; c++)
+        if (sh[c] > 0) st.W[c * 64 + lane + sh[c]] = w[c];
+    if (acc) st.W[r0 + below] = key;
+    wave_sync();
+    st.plen = plen + __popcll(A);
+    if (first < st.cursor) st.cursor = first;
 }
 
 // LAT = 0: throughput variant (many waves per CU hide the latencies; smallest register/LDS footprint).

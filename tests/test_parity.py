@@ -45,6 +45,13 @@ def test_search_parity_ef_sweep(eng, oracle, ef):
                            nq=S(kind, 5, 300), seed=ef, graph_seed=77)
 
 
+def test_search_parity_ef_beyond_merge_width(eng, oracle):
+    # W longer than the 512 entries the one-pass merge of `push` covers: the sequential insertion path
+    ida, kind = eng
+    pc.check_search_parity(ida, oracle, n=S(kind, 640, 30000), dim=S(kind, 4, 64), ef_search=S(kind, 600, 1500),
+                           nq=S(kind, 3, 64), seed=41)
+
+
 def test_search_parity_heavy_ties(eng, oracle):
     # few distinct coordinates => many exactly equal distances: exercises the distance-only
     # break test (core/lib.rs:600-604) and the (distance, pid) tie-break (core/types.rs:229-234)
