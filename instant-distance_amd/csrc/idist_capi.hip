@@ -248,10 +248,12 @@ idist_status load_points_host(idist_index* ix, const float* h_nat) {
 }
 
 uint32_t default_slots(const idist_index* ix) {
-    // fill the chip (16 single-wave workgroups per CU) within a visited-set memory budget
+    // fill the chip (16 single-wave workgroups per CU) within a visited-set memory budget: one byte per point
+    // and slot (core/types.rs:13-59), so beyond ~16M points the slots — not the CUs — bound the concurrency
+    // (100M points: 64 GB buy 640 slots)
     size_t freeb = 0, totalb = 0;
     if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) freeb = (size_t)8 << 30;
-    const size_t budget = std::min<size_t>(freeb / 4, (size_t)32 << 30);
+    const size_t budget = std::min<size_t>(freeb / 3, (size_t)64 << 30);
     const size_t vis = (((size_t)ix->n + 255) & ~(size_t)255);
     size_t s = (size_t)ix->n_cu * 16;
     if (vis) s = std::min(s, std::max<size_t>(budget / vis, 64));
