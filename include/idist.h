@@ -142,6 +142,19 @@ idist_status idist_index_build_device(const void* d_points, uint32_t n, uint32_t
                                       const idist_config* cfg, int32_t device, idist_index** out);
 idist_status idist_index_build_stats(const idist_index* idx, idist_build_stats* out);
 
+/* Builder::progress (core/lib.rs:70-75 behind the `indicatif` feature; the bar is advanced at :217-221,
+ * :306-309, :332-334, :520-526).  No callbacks cross this ABI, so progress is a pollable object: create it,
+ * arm it on the thread that is about to call idist_index_build*, and read it from any other thread while
+ * that (blocking) call runs.  `total` = points.len() (bar.set_length, :219), `done` = points inserted so
+ * far (the bar's position), `layer` = the layer being built (the bar's message, :307), -1 before the first
+ * and after the last.  The device advances it after every build step. */
+typedef struct idist_progress idist_progress;
+idist_status idist_progress_new(idist_progress** out);
+void idist_progress_free(idist_progress* p);
+/* the next idist_index_build / idist_index_build_device call made by THIS thread reports into `p` */
+idist_status idist_progress_watch_next_build(idist_progress* p);
+idist_status idist_progress_get(const idist_progress* p, uint64_t* done, uint64_t* total, int32_t* layer);
+
 /* Adopt an existing graph: the fields of `struct Hnsw`, core/lib.rs:194-199
  * (points, zero: Vec<ZeroNode>, layers: Vec<Vec<UpperNode>>).  Rows are validated
  * against the reference's invariants (ids < n, no duplicate before the first INVALID). */

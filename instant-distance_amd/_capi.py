@@ -84,6 +84,10 @@ SYMBOLS = {
     "idist_index_build": (C.c_int32, [_f32p, C.c_uint32, C.c_uint32, C.POINTER(Config), C.c_int32, C.POINTER(_vp)]),
     "idist_index_build_device": (C.c_int32, [_vp, C.c_uint32, C.c_uint32, C.POINTER(Config), C.c_int32, C.POINTER(_vp)]),
     "idist_index_build_stats": (C.c_int32, [_vp, C.POINTER(BuildStats)]),
+    "idist_progress_new": (C.c_int32, [C.POINTER(_vp)]),
+    "idist_progress_free": (None, [_vp]),
+    "idist_progress_watch_next_build": (C.c_int32, [_vp]),
+    "idist_progress_get": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     "idist_index_import": (C.c_int32, [_f32p, C.c_uint32, C.c_uint32, C.POINTER(Config), _u32p, C.POINTER(_u32p), _u32p,
                                        C.c_uint32, C.c_int32, C.POINTER(_vp)]),
     "idist_index_alloc": (C.c_int32, [C.c_uint32, C.c_uint32, C.POINTER(Config), _u32p, C.c_uint32, C.c_int32, C.POINTER(_vp)]),

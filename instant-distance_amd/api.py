@@ -55,6 +55,7 @@ class Builder:
         self._metric = METRIC_L2SQ
         self._max_batch = 0
         self._device = 0
+        self._progress = None
 
     @classmethod
     def default(cls) -> "Builder":
@@ -79,6 +80,14 @@ class Builder:
 
     def seed(self, seed: int) -> "Builder":
         self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        return self
+
+    def progress(self, bar) -> "Builder":
+        """Builder::progress (core/lib.rs:70-75, `indicatif` feature): track the construction.  `bar` is a
+        callable `bar(done, total, layer)` — the bar's position, length and the layer named in its message
+        (`layer` is None outside the per-layer loop) — called from a watcher thread while the build runs and
+        once more when it is finished (`bar.finish()`, :332-334)."""
+        self._progress = bar
         return self
 
     # -- additions of this engine --
@@ -119,6 +128,54 @@ class Builder:
     def build_hnsw(self, points) -> tuple["Hnsw", list[PointId]]:
         """Builder::build_hnsw (core/lib.rs:83-85): (index, original index -> PointId)."""
         return Hnsw._new(points, self)
+
+
+class _BuildWatch:
+    """Arms an idist_progress for the build call of this thread and polls it from a watcher thread."""
+
+    def __init__(self, bar, period: float = 0.05):
+        self.bar, self.period, self.h, self._stop, self._thr = bar, period, None, None, None
+
+    def __enter__(self):
+        if self.bar is None:
+            return self
+        import threading
+
+        L = _lib()
+        h = C.c_void_p()
+        L.check(L.idist_progress_new(C.byref(h)))
+        self.h = h
+        L.check(L.idist_progress_watch_next_build(h))
+        self._stop = threading.Event()
+
+        def poll():
+            last = None
+            while not self._stop.wait(self.period):
+                cur = self._read()
+                if cur != last and cur[1]:
+                    self.bar(*cur)
+                    last = cur
+
+        self._thr = threading.Thread(target=poll, daemon=True)
+        self._thr.start()
+        return self
+
+    def _read(self):
+        d, t, l = C.c_uint64(0), C.c_uint64(0), C.c_int32(-1)
+        _lib().idist_progress_get(self.h, C.byref(d), C.byref(t), C.byref(l))
+        return int(d.value), int(t.value), (int(l.value) if l.value >= 0 else None)
+
+    def __exit__(self, et, ev, tb):
+        if self.h is None:
+            return False
+        self._stop.set()
+        self._thr.join()
+        _lib().idist_progress_watch_next_build(None)     # disarm if the build call never consumed it
+        if et is None:
+            self.bar(*self._read())                       # finish: done == total
+        _lib().idist_progress_free(self.h)
+        self.h = None
+        return False
 
 
 class Search:
@@ -257,7 +314,8 @@ class Hnsw:
         cfg = builder._config()
         h = C.c_void_p()
         L = _lib()
-        L.check(L.idist_index_build(_capi.f32p(pts), n, max(dim, 1), C.byref(cfg), builder._device, C.byref(h)))
+        with _BuildWatch(builder._progress):
+            L.check(L.idist_index_build(_capi.f32p(pts), n, max(dim, 1), C.byref(cfg), builder._device, C.byref(h)))
         return cls(h, pts, builder._ef_search)
 
     @classmethod
@@ -268,7 +326,8 @@ class Hnsw:
         cfg = builder._config()
         h = C.c_void_p()
         L = _lib()
-        L.check(L.idist_index_build_device(C.c_void_p(d_points_ptr), n, dim, C.byref(cfg), builder._device, C.byref(h)))
+        with _BuildWatch(builder._progress):
+            L.check(L.idist_index_build_device(C.c_void_p(d_points_ptr), n, dim, C.byref(cfg), builder._device, C.byref(h)))
         pts = host_points if host_points is not None else np.zeros((n, 0), dtype=np.float32)
         return cls(h, pts, builder._ef_search)
 

@@ -26,6 +26,7 @@ using namespace idist;
 namespace {
 
 thread_local std::string g_err;
+thread_local struct idist_progress* g_watch = nullptr;   // armed by idist_progress_watch_next_build
 
 idist_status fail(idist_status st, const char* fmt, ...) {
     char buf[512];
@@ -151,6 +152,11 @@ struct idist_index {
         v.metric = (uint32_t)cfg.metric;
         return v;
     }
+};
+
+struct idist_progress {
+    volatile unsigned long long* slot = nullptr;   // pinned host memory the device writes: [0] done, [1] layer + 1
+    unsigned long long total = 0;
 };
 
 struct idist_search_ctx {
@@ -282,8 +288,9 @@ idist_status device_status_to_code(uint32_t st) {
 }
 
 // ---- build driver: the per-layer insertion schedule of Hnsw::new, core/lib.rs:304-329 ----
-idist_status run_build(idist_index* ix) {
+idist_status run_build(idist_index* ix, idist_progress* prog) {
     const uint32_t n = ix->n;
+    if (prog) { prog->total = n; prog->slot[0] = n ? 1 : 0; prog->slot[1] = 0; }   // pid 0 is in from the start
     if (n <= 1) return IDIST_OK;   // pid 0 is never inserted (core/lib.rs:279-280)
     const idist_config& cfg = ix->cfg;
     const uint32_t top = ix->n_upper;
@@ -450,6 +457,7 @@ idist_status run_build(idist_index* ix) {
 #undef LAUNCH_BUILD
             g += B;
             n_batches++;
+            if (prog) IDIST_LAUNCH(progress_kernel, 1, 1, 0, stream, prog->slot, (unsigned long long)g, (unsigned long long)layer + 1ull);
             if ((n_batches & 1023u) == 0) BCHK(hipGetLastError());
         }
         if (layer > 0) {                                                 // UpperNode::from_zero, :323-328
@@ -479,6 +487,7 @@ idist_status run_build(idist_index* ix) {
     ix->stats.seconds = ms * 1e-3;
     ix->stats.n_updates_fast = stats[6];
     ix->stats.n_updates_full = stats[7];
+    if (prog) { prog->slot[0] = n; prog->slot[1] = 0; }
     return device_status_to_code(small[6]);
 }
 
@@ -496,7 +505,9 @@ idist_status build_common(const void* points, bool on_device, uint32_t n, uint32
     idist_index* ix = nullptr;
     CHK(index_alloc(n, dim, cfg, cum + 1, n ? nl - 1 : 0, device, &ix));
     idist_status s = on_device ? load_points_device(ix, (const float*)points) : load_points_host(ix, (const float*)points);
-    if (s == IDIST_OK) s = run_build(ix);
+    idist_progress* prog = g_watch;
+    g_watch = nullptr;
+    if (s == IDIST_OK) s = run_build(ix, prog);
     if (s != IDIST_OK) { idist_index_free(ix); return s; }
     *out = ix;
     return IDIST_OK;
@@ -634,6 +645,40 @@ idist_status idist_index_build_device(const void* d_points, uint32_t n, uint32_t
     if (!out) return fail(IDIST_ERR_INVALID_ARG, "out is null");
     *out = nullptr;
     return build_common(d_points, true, n, dim, cfg, device, out);
+}
+
+idist_status idist_progress_new(idist_progress** out) {
+    if (!out) return fail(IDIST_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    idist_progress* p = new idist_progress();
+    void* m = nullptr;
+    hipError_t e = hipHostMalloc(&m, 64, hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) { delete p; return fail(IDIST_ERR_HIP, "hipHostMalloc(progress): %s", hipGetErrorString(e)); }
+    p->slot = reinterpret_cast<volatile unsigned long long*>(m);
+    p->slot[0] = 0;
+    p->slot[1] = 0;
+    *out = p;
+    return IDIST_OK;
+}
+
+void idist_progress_free(idist_progress* p) {
+    if (!p) return;
+    if (g_watch == p) g_watch = nullptr;
+    if (p->slot) hipHostFree(const_cast<unsigned long long*>(p->slot));
+    delete p;
+}
+
+idist_status idist_progress_watch_next_build(idist_progress* p) {
+    g_watch = p;
+    return IDIST_OK;
+}
+
+idist_status idist_progress_get(const idist_progress* p, uint64_t* done, uint64_t* total, int32_t* layer) {
+    if (!p) return fail(IDIST_ERR_INVALID_ARG, "progress is null");
+    if (done) *done = p->slot[0];
+    if (total) *total = p->total;
+    if (layer) *layer = (int32_t)p->slot[1] - 1;
+    return IDIST_OK;
 }
 
 idist_status idist_index_build_stats(const idist_index* idx, idist_build_stats* out) {

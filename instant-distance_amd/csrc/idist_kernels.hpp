@@ -33,6 +33,13 @@ __global__ void snapshot_kernel(const uint32_t* __restrict__ zero, uint32_t* __r
     }
 }
 
+// Builder::progress: one thread publishes {done, layer} to pinned host memory after a build step
+__global__ void progress_kernel(volatile unsigned long long* slot, unsigned long long done, unsigned long long layer) {
+    slot[0] = done;
+    slot[1] = layer;
+    __threadfence_system();
+}
+
 // Reference invariants of an adjacency array: ids < limit, no duplicate before the
 // first INVALID (Visited makes duplicates impossible in the reference builder).
 __global__ __launch_bounds__(64) void validate_rows_kernel(const uint32_t* __restrict__ rows, uint32_t n_rows,

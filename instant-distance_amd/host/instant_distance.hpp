@@ -19,10 +19,15 @@
 // idist_status is thrown as instant_distance::Error (the shim's `expect()`).
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <exception>
+#include <functional>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -118,6 +123,9 @@ public:
     }
     Builder ml(float ml) && { cfg_.ml = ml; return std::move(*this); }                                          // :57-60
     Builder seed(uint64_t s) && { seed_ = s; return std::move(*this); }                                         // :65-68
+    // :70-75 (`indicatif` feature): bar(done, total, layer) is called from a watcher thread while the build runs
+    // and once more when it has finished; layer < 0 outside the per-layer loop
+    Builder progress(std::function<void(uint64_t, uint64_t, int)> bar) && { progress_ = std::move(bar); return std::move(*this); }
     // engine knobs (not in the reference)
     Builder max_batch(uint32_t k) && { cfg_.max_batch = k; return std::move(*this); }
     Builder device(int d) && { device_ = d; return std::move(*this); }
@@ -136,6 +144,43 @@ private:
     idist_config cfg_{};
     uint64_t seed_ = 0;
     int device_ = 0;
+    std::function<void(uint64_t, uint64_t, int)> progress_;
+};
+
+// polls an idist_progress from a second thread while the blocking build call runs on the caller's
+class BuildWatch {
+public:
+    explicit BuildWatch(const std::function<void(uint64_t, uint64_t, int)>& bar) : bar_(bar) {
+        if (!bar_) return;
+        check(idist_progress_new(&p_));
+        check(idist_progress_watch_next_build(p_));
+        thr_ = std::thread([this] {
+            uint64_t last = ~0ull;
+            while (!stop_.load()) {
+                uint64_t done = 0, total = 0;
+                int32_t layer = -1;
+                idist_progress_get(p_, &done, &total, &layer);
+                if (total && done != last) { bar_(done, total, layer); last = done; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            }
+        });
+    }
+    ~BuildWatch() {
+        if (!p_) return;
+        stop_.store(true);
+        thr_.join();
+        idist_progress_watch_next_build(nullptr);
+        uint64_t done = 0, total = 0;
+        int32_t layer = -1;
+        idist_progress_get(p_, &done, &total, &layer);
+        if (!std::uncaught_exceptions()) bar_(done, total, layer);   // bar.finish()
+        idist_progress_free(p_);
+    }
+private:
+    std::function<void(uint64_t, uint64_t, int)> bar_;
+    idist_progress* p_ = nullptr;
+    std::atomic<bool> stop_{false};
+    std::thread thr_;
 };
 
 // core/lib.rs:194-397
@@ -153,7 +198,10 @@ public:
         idist_config cfg = b.cfg_;
         cfg.metric = P::METRIC;
         ef_search_ = cfg.ef_search;
-        check(idist_index_build(flat.data(), n, dim, &cfg, b.device_, &idx_));
+        {
+            BuildWatch watch(b.progress_);
+            check(idist_index_build(flat.data(), n, dim, &cfg, b.device_, &idx_));
+        }
         if (out_ids) {
             out_ids->resize(n);
             for (uint32_t i = 0; i < n; i++) (*out_ids)[i] = PointId{out[i]};

@@ -29,6 +29,7 @@ pub struct IdistConfig {
 }
 #[repr(C)] struct IdistIndex { _p: [u8; 0] }
 #[repr(C)] struct IdistSearchCtx { _p: [u8; 0] }
+#[repr(C)] struct IdistProgress { _p: [u8; 0] }
 
 extern "C" {
     fn idist_last_error() -> *const c_char;
@@ -36,6 +37,10 @@ extern "C" {
     fn idist_index_build(points: *const f32, n: u32, dim: u32, cfg: *const IdistConfig, device: i32,
                          out: *mut *mut IdistIndex) -> i32;
     fn idist_index_free(idx: *mut IdistIndex);
+    #[cfg(feature = "indicatif")] fn idist_progress_new(out: *mut *mut IdistProgress) -> i32;
+    #[cfg(feature = "indicatif")] fn idist_progress_free(p: *mut IdistProgress);
+    #[cfg(feature = "indicatif")] fn idist_progress_watch_next_build(p: *mut IdistProgress) -> i32;
+    #[cfg(feature = "indicatif")] fn idist_progress_get(p: *const IdistProgress, done: *mut u64, total: *mut u64, layer: *mut i32) -> i32;
     fn idist_search_ctx_new(idx: *const IdistIndex, slots: u32, out: *mut *mut IdistSearchCtx) -> i32;
     fn idist_search_ctx_free(ctx: *mut IdistSearchCtx);
     fn idist_search_batch(idx: *const IdistIndex, ctx: *mut IdistSearchCtx, queries: *const f32, nq: u32,
@@ -79,12 +84,15 @@ impl Default for Heuristic { fn default() -> Self { Heuristic { extend_candidate
 
 /// lib.rs:23-113
 #[derive(Clone)]
-pub struct Builder { cfg: IdistConfig, seed: u64, device: i32 }
+pub struct Builder {
+    cfg: IdistConfig, seed: u64, device: i32,
+    #[cfg(feature = "indicatif")] progress: Option<indicatif::ProgressBar>,   // lib.rs:29-30
+}
 impl Default for Builder {
     fn default() -> Self {
         let mut cfg = unsafe { std::mem::zeroed::<IdistConfig>() };
         expect(unsafe { idist_default_config(&mut cfg) });
-        Self { cfg, seed: rand::random(), device: 0 }
+        Self { cfg, seed: rand::random(), device: 0, #[cfg(feature = "indicatif")] progress: None }
     }
 }
 impl Builder {
@@ -97,6 +105,9 @@ impl Builder {
     }
     pub fn ml(mut self, ml: f32) -> Self { self.cfg.ml = ml; self }                                         // :57-60
     pub fn seed(mut self, seed: u64) -> Self { self.seed = seed; self }                                     // :65-68
+    /// A `ProgressBar` to track `Hnsw` construction progress, lib.rs:70-75
+    #[cfg(feature = "indicatif")]
+    pub fn progress(mut self, bar: indicatif::ProgressBar) -> Self { self.progress = Some(bar); self }
     pub fn build<P: Point, V: Clone>(self, points: Vec<P>, values: Vec<V>) -> HnswMap<P, V> { HnswMap::new(points, values, self) } // :78-80
     pub fn build_hnsw<P: Point>(self, points: Vec<P>) -> (Hnsw<P>, Vec<PointId>) { Hnsw::new(points, self) } // :83-85
     #[doc(hidden)]
@@ -131,7 +142,37 @@ impl<P: Point> Hnsw<P> {
         let mut cfg = builder.cfg;
         cfg.metric = P::METRIC;
         let mut idx = std::ptr::null_mut();
+        // lib.rs:217-221, :306-309, :332-334: the bar is driven from a watcher thread that polls the engine's
+        // progress object while the (blocking) build call runs on this thread
+        #[cfg(feature = "indicatif")]
+        let watch = builder.progress.clone().map(|bar| {
+            let mut p = std::ptr::null_mut();
+            expect(unsafe { idist_progress_new(&mut p) });
+            expect(unsafe { idist_progress_watch_next_build(p) });
+            bar.set_length(points.len() as u64);
+            bar.set_message("Build index (preparation)");
+            let stop = std::sync::Arc::new(std::sync::atomic::AtomicBool::new(false));
+            let (stop2, addr) = (stop.clone(), p as usize);
+            let thr = std::thread::spawn(move || {
+                let p = addr as *const IdistProgress;
+                while !stop2.load(std::sync::atomic::Ordering::Relaxed) {
+                    let (mut done, mut total, mut layer) = (0u64, 0u64, -1i32);
+                    unsafe { idist_progress_get(p, &mut done, &mut total, &mut layer) };
+                    if layer >= 0 { bar.set_message(format!("Building index (layer {})", layer)); }
+                    bar.set_position(done);
+                    std::thread::sleep(std::time::Duration::from_millis(50));
+                }
+                bar.finish();
+            });
+            (p, stop, thr)
+        });
         expect(unsafe { idist_index_build(flat.as_ptr(), points.len() as u32, dim as u32, &cfg, builder.device, &mut idx) });
+        #[cfg(feature = "indicatif")]
+        if let Some((p, stop, thr)) = watch {
+            stop.store(true, std::sync::atomic::Ordering::Relaxed);
+            let _ = thr.join();
+            unsafe { idist_progress_free(p) };
+        }
         (Self { idx, points, ef_search: cfg.ef_search as usize, dim }, out)
     }
 

@@ -87,6 +87,14 @@ int main(int argc, char** argv) {
         randomized(Builder::default_().select_heuristic(&h), 1, 64);
         REQUIRE(false);
     } catch (const Error& e) { REQUIRE(e.status == IDIST_ERR_UNSUPPORTED); }
+    // Builder::progress (core/lib.rs:70-75): position ends at the length, never goes back
+    {
+        std::vector<std::pair<uint64_t, uint64_t>> seen;
+        randomized(Builder::default_().progress([&](uint64_t done, uint64_t total, int) { seen.push_back({done, total}); }), 5, n);
+        REQUIRE(!seen.empty());
+        REQUIRE(seen.back().first == (uint64_t)n && seen.back().second == (uint64_t)n);
+        for (size_t i = 1; i < seen.size(); i++) REQUIRE(seen[i - 1].first <= seen[i].first);
+    }
     // examples/colors.rs
     std::vector<Color> colors = {{255, 0, 0}, {0, 255, 0}, {0, 0, 255}};
     std::vector<std::string> names = {"red", "green", "blue"};

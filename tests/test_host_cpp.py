@@ -15,7 +15,7 @@ def _build_and_run(lib_path, n, tmp_path):
     exe = str(tmp_path / "host_all")
     libdir, libname = os.path.dirname(lib_path), os.path.basename(lib_path)[3:-3]
     subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "host", "all.cpp"), "-o", exe,
-                           f"-L{libdir}", f"-l{libname}", f"-Wl,-rpath,{libdir}"])
+                           f"-L{libdir}", f"-l{libname}", f"-Wl,-rpath,{libdir}", "-pthread"])
     out = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "host api ok" in out.stdout

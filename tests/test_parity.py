@@ -453,3 +453,25 @@ def test_index_shared_by_threads_gpu(engine_loader, oracle):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_builder_progress(eng, oracle):
+    """Builder::progress (core/lib.rs:70-75): position never goes back, length = points.len(), ends at the length
+    (`bar.finish()`), layers are reported top-down; the index is the same with or without a bar."""
+    ida, kind = eng
+    n = S(kind, 200, 200000)
+    pts = pc.gen_points(np.random.default_rng(12), n, S(kind, 5, 64))
+    seen = []
+    b = ida.Builder().max_batch(S(kind, 1, 0)).progress(lambda done, total, layer: seen.append((done, total, layer)))
+    h = ida.Hnsw.from_ordered_points(pts, b)
+    assert seen and seen[-1][:2] == (n, n) and seen[-1][2] is None
+    assert all(t == n for _, t, _ in seen)
+    assert all(a[0] <= c[0] for a, c in zip(seen, seen[1:]))
+    layers = [l for _, _, l in seen if l is not None]
+    assert all(a >= c for a, c in zip(layers, layers[1:]))
+    zero, _ = h.into_parts()
+    zero2, _ = ida.Hnsw.from_ordered_points(pts, ida.Builder().max_batch(S(kind, 1, 0))).into_parts()
+    assert np.array_equal(zero, zero2)
+    # a watch that is never consumed must not leak into a later build of the same thread
+    h2 = ida.Hnsw.from_ordered_points(pts[:50], ida.Builder())
+    assert len(h2) == 50
