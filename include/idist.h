@@ -23,11 +23,14 @@
  *   - there is no CPU fallback: without a gfx950 device every compute entry
  *     point fails with IDIST_ERR_NO_DEVICE.
  *
- * Environment knobs (measurement and test only; none changes a result):
+ * Environment knobs (measurement and test only; none changes a search result or an exact-mode build):
  *   IDIST_LATENCY_NQ=<n>   batches of <= n queries (and build steps of <= n inserts) run the latency
  *                          variant of the graph walk; default 1024, 0 = never
  *   IDIST_BLOOM=0          no LDS Bloom filter in front of the visited bytes
  *   IDIST_BRUTEFORCE=scan|mfma, IDIST_BF_SAMPLE=<n>   force a path of idist_bruteforce / its sample size
+ *   IDIST_BUILD_PIPELINE=0 concurrent builds without the two-stream pipeline (a new point then sees all
+ *                          points up to the previous step instead of the one before; graphs differ, quality
+ *                          does not)
  *   IDIST_BUILD_RT, IDIST_BUILD_RT2, IDIST_BUILD_NO_FAST, IDIST_BUILD_CHUNK  build tile sizes / route every
  *                          neighbour update through the from-scratch kernel / updates per work-queue dequeue
  */

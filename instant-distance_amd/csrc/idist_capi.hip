@@ -331,7 +331,21 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     const size_t n_edges = (size_t)cap * IDIST_M2;
     const size_t n_touch = std::min<size_t>(n_edges, n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    // Pipelined schedule (default for concurrent builds with the heuristic): the descents of step k+1 (HBM-bound)
+    // run on one stream while the selections / neighbour updates of step k (LDS- and latency-bound) run on another.
+    // Step k's descents read the graph as of step k-2, so nothing they read is being written: the zero layer is
+    // kept in two copies, copy k&1 receiving the state after step k.  Deterministic like the sequential schedule;
+    // a new point then misses the last two steps' points (<= 1/16 of the graph) instead of the last one's.
+    bool pipe = cap > 1 && cfg.has_heuristic;
+    if (const char* e = getenv("IDIST_BUILD_PIPELINE")) pipe = pipe && e[0] != '0';
+    uint32_t* d_zero2 = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    hipEvent_t evA[2] = {nullptr, nullptr}, evS[2] = {nullptr, nullptr};
     auto release = [&]() {
+        hipFree(d_zero2);
+        if (s1) hipStreamDestroy(s1);
+        if (s2) hipStreamDestroy(s2);
+        for (int i = 0; i < 2; i++) { if (evA[i]) hipEventDestroy(evA[i]); if (evS[i]) hipEventDestroy(evS[i]); }
         hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount); hipFree(d_dlog);
         hipFree(d_vis); hipFree(d_gen); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
@@ -357,9 +371,17 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     BCHK(hipMalloc((void**)&d_row_nsel, (size_t)n * 4));
     BCHK(hipMemset(d_row_nsel, 0, (size_t)n * 4));
     BCHK(hipMalloc((void**)&d_slow, n_touch * 4));
-    BCHK(hipMalloc((void**)&d_wbuf, (size_t)cap * cfg.ef_construction * 8));
-    BCHK(hipMalloc((void**)&d_wcount, (size_t)cap * 4));
-    BCHK(hipMalloc((void**)&d_dlog, (size_t)cap * kDlogCap * 8));
+    const size_t np = pipe ? 2 : 1;       // step-A outputs are double-buffered in the pipelined schedule
+    BCHK(hipMalloc((void**)&d_wbuf, np * cap * cfg.ef_construction * 8));
+    BCHK(hipMalloc((void**)&d_wcount, np * cap * 4));
+    BCHK(hipMalloc((void**)&d_dlog, np * cap * kDlogCap * 8));
+    if (pipe) {
+        BCHK(hipMalloc((void**)&d_zero2, (size_t)n * IDIST_M2 * 4));
+        BCHK(hipMemset(d_zero2, 0xFF, (size_t)n * IDIST_M2 * 4));
+        BCHK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+        BCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) { BCHK(hipEventCreate(&evA[i])); BCHK(hipEventCreate(&evS[i])); }
+    }
     BCHK(hipMalloc((void**)&d_edge_pid, n_edges * 4));
     BCHK(hipMalloc((void**)&d_edge_dist, n_edges * 4));
     BCHK(hipMalloc((void**)&d_next, n_edges * 4));
@@ -411,8 +433,14 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     cum[0] = n;
     for (uint32_t l = 1; l <= top; l++) cum[l] = ix->layer_len[l - 1];
 
-    hipStream_t stream = nullptr;
+    hipStream_t stream = pipe ? s1 : nullptr;
+    uint32_t* zbuf[2] = {ix->d_zero, pipe ? d_zero2 : ix->d_zero};     // copy k&1 holds the state after step k
+    uint32_t* const smallS = d_small + (pipe ? 16 : 0);                // step A2/B/B2 counters (own stream)
+    uint32_t* const d_status = d_small + (pipe ? 32 : 6);
+    a.n_touched = smallS;
+    a.status = d_status;
     uint64_t n_batches = 0;
+    uint32_t prev_start = 0, prev_count = 0;
     BCHK(hipEventRecord(e0, stream));
     for (int layer = (int)top; layer >= 0; layer--) {                    // core/lib.rs:304
         const uint32_t end = cum[layer];
@@ -426,15 +454,35 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
             B = std::min(B, end - g);
             a.start = g;
             a.count = B;
-            BCHK(hipMemsetAsync(d_small, 0, 24, stream));   // n_touched, queue heads, n_slow
-            BCHK(hipMemsetAsync(d_dlog, 0xFF, (size_t)B * kDlogCap * 8, stream));   // empty distance logs
+            const uint64_t k = n_batches + 1;                              // step number, 1-based
+            const int par = (int)(k & 1u);
+            hipStream_t sA = pipe ? s1 : stream, sS = pipe ? s2 : stream;
+            IndexView viewA = view, viewS = view;
+            BuildArgs aA = a;
+            if (pipe) {
+                // a sequential (B = 1) step reads the previous step's state, a concurrent one the state before that
+                const int lag = B > 1 ? 2 : 1;
+                if (k > (uint64_t)lag) BCHK(hipStreamWaitEvent(s1, evS[(k - lag) & 1u], 0));
+                viewA.zero = zbuf[(k - lag) & 1u];
+                viewS.zero = zbuf[par];
+                aA.queue = d_small + 1;
+                aA.dlog = d_dlog + (size_t)par * cap * kDlogCap;
+                aA.wbuf = d_wbuf + (size_t)par * cap * cfg.ef_construction;
+                aA.wcount = d_wcount + (size_t)par * cap;
+                BCHK(hipMemsetAsync(d_small, 0, 8, sA));                  // step A queue head
+            } else {
+                BCHK(hipMemsetAsync(d_small, 0, 24, sA));                 // n_touched, queue heads, n_slow
+            }
+            BCHK(hipMemsetAsync(aA.dlog, 0xFF, (size_t)B * kDlogCap * 8, sA));   // empty distance logs
             const uint32_t gridA = std::min(B, slots);
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
             const uint32_t gridS = std::min<uint32_t>(gridB, (uint32_t)ix->n_cu * 6);
             const uint32_t gridA2 = std::min<uint32_t>(B, (uint32_t)ix->n_cu * 4);
-            a.efc = no_fast ? 0u : cfg.ef_construction;   // efc = 0 makes the fast kernel defer everything
-            BuildArgs af = a;
-            a.efc = cfg.ef_construction;
+            BuildArgs aS = aA;                                             // same step-A outputs, own counters
+            aS.queue = smallS + 1;
+            aS.n_slow = smallS + 3;
+            BuildArgs af = aS;
+            af.efc = no_fast ? 0u : cfg.ef_construction;                  // efc = 0 makes the fast kernel defer everything
 #define LAUNCH_BUILD(NB_, RS_, TAIL_)                                                              \
     {                                                                                              \
         auto kA = build_insert_kernel<NB_, RS_, TAIL_, 0>;                                         \
@@ -443,28 +491,42 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
         auto kA2 = build_select_kernel<NB_, RS_, TAIL_>;                                           \
-        if (B <= lat_nq) { IDIST_LAUNCH(kAl, gridA, 64, smem_lat, stream, view, a); }              \
-        else { IDIST_LAUNCH(kA, gridA, 64, smem, stream, view, a); }                               \
+        if (B <= lat_nq) { IDIST_LAUNCH(kAl, gridA, 64, smem_lat, sA, viewA, aA); }                \
+        else { IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA); }                                 \
+        if (pipe) {                                                                                \
+            BCHK(hipEventRecord(evA[par], s1));                                                    \
+            BCHK(hipStreamWaitEvent(s2, evA[par], 0));                                             \
+            IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s2, zbuf[par ^ 1], zbuf[par], a.touched, smallS, prev_start, prev_count); \
+            BCHK(hipMemsetAsync(smallS, 0, 24, s2));                                               \
+        }                                                                                          \
         if (cfg.has_heuristic) {                                                                   \
-            IDIST_LAUNCH(kA2, gridA2, 64, smemA2, stream, view, a);                                \
-            IDIST_LAUNCH(kF, gridB, 64, smemF, stream, view, af);                                  \
-            IDIST_LAUNCH(kB, gridS, 64, smemB, stream, view, a);                                   \
+            IDIST_LAUNCH(kA2, gridA2, 64, smemA2, sS, viewS, aS);                                  \
+            IDIST_LAUNCH(kF, gridB, 64, smemF, sS, viewS, af);                                     \
+            IDIST_LAUNCH(kB, gridS, 64, smemB, sS, viewS, aS);                                     \
         } else {                                                                                   \
-            IDIST_LAUNCH(kP, gridB, 64, (size_t)(72 * 8 + 64 * 4), stream, view, a);               \
+            IDIST_LAUNCH(kP, gridB, 64, (size_t)(72 * 8 + 64 * 4), sS, viewS, aS);                 \
         }                                                                                          \
     }
             IDIST_DISPATCH(ix->L, LAUNCH_BUILD);
 #undef LAUNCH_BUILD
+            prev_start = g;
+            prev_count = B;
             g += B;
             n_batches++;
-            if (prog) IDIST_LAUNCH(progress_kernel, 1, 1, 0, stream, prog->slot, (unsigned long long)g, (unsigned long long)layer + 1ull);
+            if (prog) IDIST_LAUNCH(progress_kernel, 1, 1, 0, sS, prog->slot, (unsigned long long)g, (unsigned long long)layer + 1ull);
+            if (pipe) BCHK(hipEventRecord(evS[par], s2));
             if ((n_batches & 1023u) == 0) BCHK(hipGetLastError());
         }
         if (layer > 0) {                                                 // UpperNode::from_zero, :323-328
             const size_t total = (size_t)end * IDIST_M;
             const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
-            IDIST_LAUNCH(snapshot_kernel, grid, 256, 0, stream, ix->d_zero, ix->d_upper + ix->layer_off[layer - 1] * IDIST_M, end);
+            if (pipe && n_batches) BCHK(hipStreamWaitEvent(s1, evS[n_batches & 1u], 0));   // the layer is complete
+            IDIST_LAUNCH(snapshot_kernel, grid, 256, 0, stream, zbuf[n_batches & 1u], ix->d_upper + ix->layer_off[layer - 1] * IDIST_M, end);
         }
+    }
+    if (pipe) {
+        if (n_batches) BCHK(hipStreamWaitEvent(s1, evS[n_batches & 1u], 0));
+        if (n_batches & 1u) std::swap(ix->d_zero, d_zero2);              // the final state lives in copy (last step)&1
     }
     BCHK(hipEventRecord(e1, stream));
     BCHK(hipGetLastError());
@@ -473,7 +535,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     BCHK(hipEventElapsedTime(&ms, e0, e1));
     uint32_t small[8] = {0};
     unsigned long long stats[8] = {0};
-    BCHK(hipMemcpy(small, d_small, 32, hipMemcpyDeviceToHost));
+    BCHK(hipMemcpy(&small[6], d_status, 4, hipMemcpyDeviceToHost));
     BCHK(hipMemcpy(stats, d_stats, 64, hipMemcpyDeviceToHost));
 #undef BCHK
     release();

@@ -33,6 +33,18 @@ __global__ void snapshot_kernel(const uint32_t* __restrict__ zero, uint32_t* __r
     }
 }
 
+// Pipelined build: the rows step k-1 rewrote (its new nodes [start, start+count) and the nodes on its touched
+// list) are carried over into the other copy of the zero layer before step k works on that copy in place.
+__global__ __launch_bounds__(64) void copy_rows_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                      const uint32_t* __restrict__ touched, const uint32_t* n_touched,
+                                                      uint32_t start, uint32_t count) {
+    const uint32_t total = count + *n_touched;
+    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+        const uint32_t row = i < count ? start + i : touched[i - count];
+        dst[(size_t)row * kM2 + threadIdx.x] = src[(size_t)row * kM2 + threadIdx.x];
+    }
+}
+
 // Builder::progress: one thread publishes {done, layer} to pinned host memory after a build step
 __global__ void progress_kernel(volatile unsigned long long* slot, unsigned long long done, unsigned long long layer) {
     slot[0] = done;

@@ -170,8 +170,11 @@ def test_c2_full_size_properties_gpu(engine_loader, oracle):
     assert pc.recall_at(got.pid[:300], truth, 10) > 0.5       # uniform 128-d data: high intrinsic dimension
 
 
-def test_build_batched(eng, oracle):
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_build_batched(eng, oracle, monkeypatch, pipeline):
+    # both schedules of a concurrent build: pipelined (descents of step k+1 overlap the updates of step k) and not
     ida, kind = eng
+    monkeypatch.setenv("IDIST_BUILD_PIPELINE", pipeline)
     rec = pc.check_build_batched(ida, oracle, n=S(kind, 220, 30000), dim=S(kind, 4, 32), max_batch=S(kind, 4, 0),
                                  nq=S(kind, 20, 500))
     assert rec >= 0.95
