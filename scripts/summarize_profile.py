@@ -70,6 +70,22 @@ try:
     res["bench"] = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
 except Exception as e:  # noqa: BLE001
     res["bench_error"] = str(e)
+# the bench line printed by the TRACED run itself: its HIP-event kernel time must agree with the trace
+try:
+    for line in open(os.path.join(out, "trace.log")):
+        if line.startswith('{"metric"'):
+            res["bench_traced_run"] = json.loads(line)
+    for f in dbs("trace"):
+        cur = sqlite3.connect(f).cursor()
+        d = [r[0] for r in cur.execute("select end - start from kernels where name like '%search_kernel%' and name like '%, 0>%' order by start")]
+        steps = res.get("bench_traced_run", {}).get("steps", 5)
+        if len(d) >= steps + 1:
+            timed = d[-(steps + 1):-1]      # the last launch restores the outputs after the single-query probes
+            res["agreement"] = {"rocprof_avg_ms_of_the_timed_launches": round(sum(timed) / len(timed) / 1e6, 3),
+                                "bench_hip_event_avg_ms_same_run": res["bench_traced_run"]["roofline"]["kernel_ms_avg"],
+                                "timed_launches": len(timed)}
+except Exception as e:  # noqa: BLE001
+    res["agreement_error"] = str(e)
 sf, sw = res["pmc_FETCH_SIZE"].get("search_kernel"), res["pmc_WRITE_SIZE"].get("search_kernel")
 if sf and sw and factor:
     fetch = sf["last_KB"] * 1024 * factor
@@ -96,5 +112,11 @@ if dest:
                 "\nWRITE_SIZE " + json.dumps(res["pmc_WRITE_SIZE"], indent=1) + "\n```\n")
         f.write("\n## FETCH_SIZE calibration on the gather pattern\n\n```\n" + json.dumps(res.get("calibration", {}), indent=1) + "\n```\n")
         f.write("\n## search_kernel HBM traffic per launch\n\n```\n" + json.dumps(res.get("traffic", {}), indent=1) + "\n```\n")
+        if "agreement" in res:
+            f.write("\n## search_kernel duration: rocprofv3 trace vs bench.py's own HIP events (the traced run)\n\n```\n" +
+                    json.dumps(res["agreement"], indent=1) + "\n```\n(clock state moves the kernel time by several % between "
+                    "runs on one box; compare numbers of the same run)\n")
         if "bench" in res:
-            f.write("\n## bench line of the same session\n\n```json\n" + json.dumps(res["bench"]) + "\n```\n")
+            f.write("\n## bench line of the same session (un-profiled run)\n\n```json\n" + json.dumps(res["bench"]) + "\n```\n")
+        if "bench_traced_run" in res:
+            f.write("\n## bench line printed by the traced run\n\n```json\n" + json.dumps(res["bench_traced_run"]) + "\n```\n")
