@@ -338,6 +338,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     // a new point then misses the last two steps' points (<= 1/16 of the graph) instead of the last one's.
     bool pipe = cap > 1 && cfg.has_heuristic;
     if (const char* e = getenv("IDIST_BUILD_PIPELINE")) pipe = pipe && e[0] != '0';
+    // the descents (8-12 waves per CU saturate their HBM stream) leave wave slots and LDS to the other stream
+    uint32_t a_waves = 10;
+    if (const char* e = getenv("IDIST_BUILD_A_WAVES")) a_waves = std::max(1, atoi(e));
     uint32_t* d_zero2 = nullptr;
     hipStream_t s1 = nullptr, s2 = nullptr;
     hipEvent_t evA[2] = {nullptr, nullptr}, evS[2] = {nullptr, nullptr};
@@ -474,7 +477,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
                 BCHK(hipMemsetAsync(d_small, 0, 24, sA));                 // n_touched, queue heads, n_slow
             }
             BCHK(hipMemsetAsync(aA.dlog, 0xFF, (size_t)B * kDlogCap * 8, sA));   // empty distance logs
-            const uint32_t gridA = std::min(B, slots);
+            const uint32_t gridA = std::min(B, pipe ? std::min<uint32_t>(slots, (uint32_t)ix->n_cu * a_waves) : slots);
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
             const uint32_t gridS = std::min<uint32_t>(gridB, (uint32_t)ix->n_cu * 6);
             const uint32_t gridA2 = std::min<uint32_t>(B, (uint32_t)ix->n_cu * 4);
