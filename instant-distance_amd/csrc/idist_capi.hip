@@ -436,6 +436,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     cum[0] = n;
     for (uint32_t l = 1; l <= top; l++) cum[l] = ix->layer_len[l - 1];
 
+    // the set-up above ran on the null stream, which the pipeline's non-blocking streams do not wait for
+    if (pipe) BCHK(hipDeviceSynchronize());
     hipStream_t stream = pipe ? s1 : nullptr;
     uint32_t* zbuf[2] = {ix->d_zero, pipe ? d_zero2 : ix->d_zero};     // copy k&1 holds the state after step k
     uint32_t* const smallS = d_small + (pipe ? 16 : 0);                // step A2/B/B2 counters (own stream)
