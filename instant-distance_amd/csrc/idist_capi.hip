@@ -886,6 +886,8 @@ idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_
         if ((e = hipEventCreate(&c->ev0[i])) != hipSuccess) return bail(e);
         if ((e = hipEventCreate(&c->ev1[i])) != hipSuccess) return bail(e);
     }
+    // the scratch above was cleared on the null stream; a caller's non-blocking stream would not wait for it
+    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(e);
     *out = c;
     return IDIST_OK;
 }
