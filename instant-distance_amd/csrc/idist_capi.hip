@@ -227,6 +227,9 @@ idist_status index_alloc(uint32_t n, uint32_t dim, const idist_config* cfg, cons
         hipMemset(ix->d_zero, 0xFF, std::max<size_t>((size_t)n * IDIST_M2 * 4, 4)) != hipSuccess ||
         hipMemset(ix->d_upper, 0xFF, std::max<size_t>(rows * IDIST_M * 4, 4)) != hipSuccess)
         return cleanup(fail(IDIST_ERR_HIP, "index initialisation failed: %s", hipGetErrorString(hipGetLastError())));
+    // callers fill these buffers from their own streams (RCCL broadcast, imports): let the fills above land first
+    if (hipDeviceSynchronize() != hipSuccess)
+        return cleanup(fail(IDIST_ERR_HIP, "index initialisation failed: %s", hipGetErrorString(hipGetLastError())));
     *out = ix;
     return IDIST_OK;
 }
