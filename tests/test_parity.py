@@ -478,3 +478,44 @@ def test_builder_progress(eng, oracle):
     # a watch that is never consumed must not leak into a later build of the same thread
     h2 = ida.Hnsw.from_ordered_points(pts[:50], ida.Builder())
     assert len(h2) == 50
+
+
+def _fuzz_cases(kind, count, seed0):
+    """Seeded random configurations: dimension classes (template / generic geometry, tails), data shapes with and
+    without exact ties, both metrics, ef values around the 64-lane boundaries."""
+    rng = np.random.default_rng(seed0)
+    dims = [1, 2, 3, 5, 8, 12, 20, 31, 64, 100, 128, 129, 300, 304, 768] if kind == "gpu" else [1, 3, 5, 12, 20, 128, 300]
+    out = []
+    for i in range(count):
+        dim = int(rng.choice(dims))
+        kind_ = str(rng.choice(["uniform", "grid", "lowrank"] if dim >= 8 else ["uniform", "grid"]))
+        n_hi = (6000 if dim <= 128 else 2500) if kind == "gpu" else 200
+        n_lo = 400 if kind == "gpu" else 90
+        out.append(dict(n=int(rng.integers(n_lo, n_hi)), dim=dim, kind=kind_, metric=int(rng.integers(0, 2)),
+                        ef=int(rng.choice([1, 3, 17, 63, 64, 65, 100, 127, 128, 129, 200, 333])),
+                        efc=int(rng.choice([8, 40, 64, 100, 130])), keep=bool(rng.integers(0, 2)), seed=seed0 * 1000 + i))
+    return out
+
+
+@pytest.mark.parametrize("case", range(3))
+def test_fuzz_search_and_exact_build_emulated(engine_loader, oracle, case):
+    ida = engine_loader("emu")
+    c = _fuzz_cases("emu", 3, 77)[case]
+    pc.check_search_parity(ida, oracle, n=c["n"], dim=c["dim"], ef_search=c["ef"], metric=c["metric"], kind=c["kind"],
+                           nq=4, seed=c["seed"], ef_construction=c["efc"])
+    pc.check_build_exact(ida, oracle, n=min(c["n"], 110), dim=c["dim"], metric=c["metric"], kind=c["kind"],
+                         ef_construction=c["efc"], keep_pruned=c["keep"], seed=c["seed"] + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(14))
+def test_fuzz_search_and_exact_build_gpu(engine_loader, oracle, case):
+    ida = engine_loader("gpu")
+    c = _fuzz_cases("gpu", 14, 78)[case]
+    try:
+        pc.check_search_parity(ida, oracle, n=c["n"], dim=c["dim"], ef_search=c["ef"], metric=c["metric"], kind=c["kind"],
+                               nq=96, seed=c["seed"], ef_construction=c["efc"])
+    except ida.IdistError as e:      # integer grids in low dimension can exceed the tie capacity: reported, never silent
+        assert e.status == 6 and c["kind"] == "grid"
+    pc.check_build_exact(ida, oracle, n=min(c["n"], 1500), dim=c["dim"], metric=c["metric"], kind=c["kind"],
+                         ef_construction=c["efc"], keep_pruned=c["keep"], seed=c["seed"] + 1)
