@@ -172,3 +172,31 @@ def check_build_batched(ida, oracle, n, dim, max_batch=0, kind="uniform", k=10, 
     z2, l2 = h2.into_parts()
     assert np.array_equal(zero, z2)
     return rec
+
+
+def check_build_concurrent_invariants(ida, oracle, n, dim, kind="uniform", metric=0, ef_construction=100, keep_pruned=True,
+                                      max_batch=0, seed=0, nq=200, k=10, slack=0.03):
+    """Default (concurrent, pipelined) build: no oracle graph to compare bytes with, so check what must hold for ANY
+    legal outcome — the reference's row invariants (re-import validates: ids in range, no duplicates before the first
+    INVALID), determinism, and recall@k no worse than the oracle's threaded build of the same points (minus slack)."""
+    rng = np.random.default_rng(seed)
+    pts = gen_points(rng, n, dim, kind)
+    q = gen_points(rng, nq, dim, kind)
+    b = (ida.Builder().metric(metric).max_batch(max_batch).ef_construction(ef_construction)
+         .select_heuristic(ida.Heuristic(False, keep_pruned)))
+    h = ida.Hnsw.from_ordered_points(pts, b)
+    zero, layers = h.into_parts()
+    zero2, layers2 = ida.Hnsw.from_ordered_points(pts, b).into_parts()
+    assert np.array_equal(zero, zero2) and all(np.array_equal(x, y) for x, y in zip(layers, layers2))
+    ida.Hnsw.from_parts(pts, zero, layers, b)                       # idist_index_import validates every row
+    assert not np.any(zero[:, 0] == INVALID) or n <= 1              # every point has a neighbour
+    own = np.arange(n, dtype=np.uint32)[:, None]
+    assert not np.any(zero == own)                                  # no self links
+    truth, _ = h.bruteforce(q, k)
+    got = h.search_batch(q, ida.Search())
+    rec = recall_at(got.pid, truth, k)
+    cfg = oracle.default_config(metric=metric, ef_construction=ef_construction, keep_pruned=int(keep_pruned))
+    oix = oracle.Index.build(pts, cfg, threads=4)
+    orec = recall_at(oix.search(q).pid, truth, k)
+    assert rec >= orec - slack, (rec, orec)
+    return rec, orec

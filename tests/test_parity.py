@@ -519,3 +519,21 @@ def test_fuzz_search_and_exact_build_gpu(engine_loader, oracle, case):
         assert e.status == 6 and c["kind"] == "grid"
     pc.check_build_exact(ida, oracle, n=min(c["n"], 1500), dim=c["dim"], metric=c["metric"], kind=c["kind"],
                          ef_construction=c["efc"], keep_pruned=c["keep"], seed=c["seed"] + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(5))
+def test_fuzz_concurrent_build_gpu(engine_loader, oracle, case):
+    ida = engine_loader("gpu")
+    c = _fuzz_cases("gpu", 5, 79)[case]
+    n = c["n"] * (12 if c["dim"] <= 128 else 6)
+    try:
+        pc.check_build_concurrent_invariants(ida, oracle, n=n, dim=c["dim"], kind=c["kind"], metric=c["metric"],
+                                             ef_construction=max(c["efc"], 40), keep_pruned=c["keep"], seed=c["seed"])
+    except ida.IdistError as e:      # dense integer grids: > 64 live equidistant candidates is reported, never silent
+        assert e.status == 6 and c["kind"] == "grid" and c["dim"] <= 8
+
+
+def test_concurrent_build_invariants_emulated(engine_loader, oracle):
+    ida = engine_loader("emu")
+    pc.check_build_concurrent_invariants(ida, oracle, n=330, dim=6, kind="grid", metric=1, max_batch=8, seed=5, nq=20, slack=0.08)
