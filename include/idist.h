@@ -63,6 +63,8 @@ enum {
     IDIST_ERR_INTERNAL = 7        /* device-side guard tripped */
 };
 
+enum { IDIST_TIES_STRICT = 0, IDIST_TIES_DROP = 1 };
+
 enum {
     IDIST_METRIC_L2SQ = 0, /* FloatArray::distance, instant-distance-py/src/lib.rs:378-421 */
     IDIST_METRIC_L2 = 1    /* sqrt of it: tests/all.rs:93-97, examples/colors.rs:21-25 */
@@ -81,6 +83,14 @@ typedef struct idist_config {
                                    deterministic contract = reference with one rayon thread);
                                    0 = library default; k = at most k concurrent inserts per
                                    step (the rayon for_each of core/lib.rs:316-318). */
+    int32_t tie_policy;         /* IDIST_TIES_*: what to do when more than 64 un-expanded candidates sit
+                                   exactly at the furthest distance of a full `nearest` (mass duplicates,
+                                   dense integer grids).  The reference's heap is unbounded; the engine's
+                                   tie region is not.  STRICT (default): fail with
+                                   IDIST_ERR_TIE_OVERFLOW — a result is either the reference's or an error.
+                                   DROP: keep the 64 smallest (distance, pid) ties, never expand the
+                                   others, and go on — deterministic, flagged in idist_build_stats /
+                                   idist_search_ctx_tie_overflowed, no longer bit-identical on such data. */
 } idist_config;
 
 typedef struct idist_index idist_index;
@@ -115,6 +125,7 @@ typedef struct idist_build_stats {
     uint64_t n_updates_full; /* ... of which through the full re-selection */
     uint64_t n_batches;
     double seconds;         /* device time of the whole build (HIP events) */
+    uint64_t tie_overflow;  /* 1 if the tie capacity was exceeded during the build (only with IDIST_TIES_DROP) */
 } idist_build_stats;
 
 /* ---- library ------------------------------------------------------------ */
@@ -200,6 +211,8 @@ idist_status idist_search_batch_device(const idist_index* idx, idist_search_ctx*
                                        void* hip_stream);
 /* Device-side status of the last launches on ctx (after the stream is synchronised). */
 idist_status idist_search_ctx_status(idist_search_ctx* ctx);
+/* IDIST_TIES_DROP only: *out = 1 if a search since the last call exceeded the tie capacity (then reset). */
+idist_status idist_search_ctx_tie_overflowed(idist_search_ctx* ctx, int32_t* out);
 /* HIP-event duration of the last search kernel launched through ctx, milliseconds. */
 idist_status idist_search_ctx_last_kernel_ms(idist_search_ctx* ctx, float* ms);
 /* Durations (ms) of the most recent search-kernel launches through ctx, oldest first, measured

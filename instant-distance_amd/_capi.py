@@ -21,6 +21,8 @@ MAX_LAYERS = 64
 MAX_EF = 4096
 METRIC_L2SQ = 0
 METRIC_L2 = 1
+TIES_STRICT = 0
+TIES_DROP = 1
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_BAD_GRAPH, ERR_TIE_OVERFLOW, ERR_INTERNAL = range(8)
 
@@ -42,6 +44,7 @@ class Config(C.Structure):
         ("keep_pruned", C.c_int32),
         ("metric", C.c_int32),
         ("max_batch", C.c_uint32),
+        ("tie_policy", C.c_int32),
     ]
 
 
@@ -66,7 +69,7 @@ class BuildStats(C.Structure):
         ("n_dist", C.c_uint64), ("n_exp0", C.c_uint64), ("n_expU", C.c_uint64),
         ("n_heur_dist", C.c_uint64), ("n_heur_rows", C.c_uint64), ("n_updates", C.c_uint64),
         ("n_updates_fast", C.c_uint64), ("n_updates_full", C.c_uint64),
-        ("n_batches", C.c_uint64), ("seconds", C.c_double),
+        ("n_batches", C.c_uint64), ("seconds", C.c_double), ("tie_overflow", C.c_uint64),
     ]
 
 
@@ -101,6 +104,7 @@ SYMBOLS = {
     "idist_search_batch": (C.c_int32, [_vp, _vp, _f32p, C.c_uint32, _u32p, _f32p, _u32p, _u32p]),
     "idist_search_batch_device": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "idist_search_ctx_status": (C.c_int32, [_vp]),
+    "idist_search_ctx_tie_overflowed": (C.c_int32, [_vp, C.POINTER(C.c_int32)]),
     "idist_search_ctx_last_kernel_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
     "idist_search_ctx_kernel_times": (C.c_int32, [_vp, _f32p, C.c_uint32, _u32p]),
     "idist_distance_batch": (C.c_int32, [_vp, _f32p, C.c_uint32, _u32p, C.c_uint32, _f32p]),

@@ -26,7 +26,7 @@ from typing import Any, Iterator, Sequence
 import numpy as np
 
 from . import _capi
-from ._capi import INVALID, M, M2, METRIC_L2, METRIC_L2SQ
+from ._capi import INVALID, M, M2, METRIC_L2, METRIC_L2SQ, TIES_DROP, TIES_STRICT
 
 PointId = int
 
@@ -56,6 +56,7 @@ class Builder:
         self._max_batch = 0
         self._device = 0
         self._progress = None
+        self._tie_policy = TIES_STRICT
 
     @classmethod
     def default(cls) -> "Builder":
@@ -96,6 +97,13 @@ class Builder:
         self._metric = int(metric)
         return self
 
+    def tie_policy(self, policy: int) -> "Builder":
+        """TIES_STRICT (default): more than 64 un-expanded candidates exactly at the furthest distance raise
+        IdistError(6) — a result is the reference's or an error.  TIES_DROP: keep the 64 nearest, go on
+        (mass-duplicate data; deterministic, flagged in build_stats().tie_overflow / Search.tie_overflowed())."""
+        self._tie_policy = int(policy)
+        return self
+
     def max_batch(self, k: int) -> "Builder":
         """1 = strictly sequential insertion (deterministic contract); 0 = default."""
         self._max_batch = int(k)
@@ -119,6 +127,7 @@ class Builder:
         c.keep_pruned = int(bool(self._heuristic.keep_pruned)) if self._heuristic else 1
         c.metric = self._metric
         c.max_batch = self._max_batch
+        c.tie_policy = self._tie_policy
         return c
 
     def build(self, points, values: Sequence[Any]) -> "HnswMap":
@@ -218,6 +227,12 @@ class Search:
         n = C.c_uint32(0)
         _lib().check(_lib().idist_search_ctx_kernel_times(self._ctx, _capi.f32p(out), last, C.byref(n)))
         return out[: n.value]
+
+    def tie_overflowed(self) -> bool:
+        """TIES_DROP only: did a search through this Search exceed the tie capacity since the last call?"""
+        out = C.c_int32(0)
+        _lib().check(_lib().idist_search_ctx_tie_overflowed(self._ctx, C.byref(out)))
+        return bool(out.value)
 
     def check_status(self):
         """Raise if a device-side guard tripped during the launches so far (after a stream sync)."""

@@ -107,6 +107,8 @@ idist_status validate_config(const idist_config* cfg, bool for_build) {
     if (cfg->ef_search > IDIST_MAX_EF) return fail(IDIST_ERR_INVALID_ARG, "ef_search %u > %u", cfg->ef_search, IDIST_MAX_EF);
     if (cfg->metric != IDIST_METRIC_L2SQ && cfg->metric != IDIST_METRIC_L2)
         return fail(IDIST_ERR_INVALID_ARG, "unknown metric %d", cfg->metric);
+    if (cfg->tie_policy != IDIST_TIES_STRICT && cfg->tie_policy != IDIST_TIES_DROP)
+        return fail(IDIST_ERR_INVALID_ARG, "unknown tie_policy %d", cfg->tie_policy);
     if (for_build) {
         if (cfg->ef_construction == 0 || cfg->ef_construction > IDIST_MAX_EF)
             return fail(IDIST_ERR_INVALID_ARG, "ef_construction %u out of [1,%u]", cfg->ef_construction, IDIST_MAX_EF);
@@ -176,6 +178,7 @@ struct idist_search_ctx {
     uint32_t* d_cnt = nullptr;
     uint32_t* d_ctr = nullptr;
     size_t cap_q = 0, cap_out = 0, cap_nq = 0;
+    bool tie_overflowed = false;
 };
 
 namespace {
@@ -282,10 +285,11 @@ bool use_bloom_filter() {
     return !(e && e[0] == '0');
 }
 
-idist_status device_status_to_code(uint32_t st) {
+idist_status device_status_to_code(uint32_t st, int32_t tie_policy) {
     if (st & kStBadRow) return fail(IDIST_ERR_BAD_GRAPH, "device met an adjacency id >= n");
-    if (st & kStTieOverflow)
-        return fail(IDIST_ERR_TIE_OVERFLOW, "more than %d live equidistant candidates beyond ef", kTieCap);
+    if ((st & kStTieOverflow) && tie_policy == IDIST_TIES_STRICT)
+        return fail(IDIST_ERR_TIE_OVERFLOW, "more than %d live equidistant candidates beyond ef "
+                    "(idist_config.tie_policy = IDIST_TIES_DROP keeps the nearest %d and goes on)", kTieCap, kTieCap);
     if (st & kStGuard) return fail(IDIST_ERR_INTERNAL, "device-side loop guard tripped");
     return IDIST_OK;
 }
@@ -558,7 +562,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     ix->stats.n_updates_fast = stats[6];
     ix->stats.n_updates_full = stats[7];
     if (prog) { prog->slot[0] = n; prog->slot[1] = 0; }
-    return device_status_to_code(small[6]);
+    ix->stats.tie_overflow = (small[6] & kStTieOverflow) ? 1 : 0;
+    return device_status_to_code(small[6], cfg.tie_policy);
 }
 
 idist_status build_common(const void* points, bool on_device, uint32_t n, uint32_t dim, const idist_config* cfg,
@@ -653,6 +658,7 @@ idist_status idist_default_config(idist_config* cfg) {   // core/lib.rs:101-128
     cfg->keep_pruned = 1;
     cfg->metric = IDIST_METRIC_L2SQ;
     cfg->max_batch = 0;
+    cfg->tie_policy = IDIST_TIES_STRICT;
     return IDIST_OK;
 }
 
@@ -936,7 +942,16 @@ idist_status idist_search_ctx_status(idist_search_ctx* ctx) {
     uint32_t st = 0;
     HIPCHK(hipMemcpy(&st, ctx->d_next + 1, 4, hipMemcpyDeviceToHost));
     if (st) HIPCHK(hipMemset(ctx->d_next + 1, 0, 4));
-    return device_status_to_code(st);
+    if (st & kStTieOverflow) ctx->tie_overflowed = true;
+    return device_status_to_code(st, ctx->idx->cfg.tie_policy);
+}
+
+idist_status idist_search_ctx_tie_overflowed(idist_search_ctx* ctx, int32_t* out) {
+    if (!ctx || !out) return fail(IDIST_ERR_INVALID_ARG, "null argument");
+    CHK(idist_search_ctx_status(ctx));
+    *out = ctx->tie_overflowed ? 1 : 0;
+    ctx->tie_overflowed = false;
+    return IDIST_OK;
 }
 
 idist_status idist_search_ctx_last_kernel_ms(idist_search_ctx* ctx, float* ms) {

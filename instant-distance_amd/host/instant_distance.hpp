@@ -128,6 +128,7 @@ public:
     Builder progress(std::function<void(uint64_t, uint64_t, int)> bar) && { progress_ = std::move(bar); return std::move(*this); }
     // engine knobs (not in the reference)
     Builder max_batch(uint32_t k) && { cfg_.max_batch = k; return std::move(*this); }
+    Builder tie_policy(int32_t p) && { cfg_.tie_policy = p; return std::move(*this); }   // IDIST_TIES_STRICT / IDIST_TIES_DROP
     Builder device(int d) && { device_ = d; return std::move(*this); }
 
     template <class P, class V> HnswMap<P, V> build(std::vector<P> points, std::vector<V> values) && {         // :78-80

@@ -537,3 +537,46 @@ def test_fuzz_concurrent_build_gpu(engine_loader, oracle, case):
 def test_concurrent_build_invariants_emulated(engine_loader, oracle):
     ida = engine_loader("emu")
     pc.check_build_concurrent_invariants(ida, oracle, n=330, dim=6, kind="grid", metric=1, max_batch=8, seed=5, nq=20, slack=0.08)
+
+
+def test_tie_policy(eng, oracle):
+    """> 64 un-expanded candidates exactly at the furthest distance (mass duplicates): STRICT reports
+    IDIST_ERR_TIE_OVERFLOW, DROP builds and searches a valid graph deterministically and flags the event."""
+    ida, kind = eng
+    rng = np.random.default_rng(3000002)
+    n = S(kind, 420, 41640)
+    pts = pc.gen_points(rng, n, S(kind, 3, 5), "grid")               # dense integer grid: masses of equal distances
+    q = pts[: S(kind, 3, 20)] + np.float32(0.25)
+    strict = (ida.Builder().metric(1).ef_search(S(kind, 8, 100)).ef_construction(S(kind, 8, 64))
+              .max_batch(S(kind, 1, 0)))
+    overflowed = False
+    try:
+        hs = ida.Hnsw.from_ordered_points(pts, strict)
+    except ida.IdistError as e:
+        assert e.status == 6
+        overflowed = True
+    if kind == "gpu":
+        assert overflowed                                                           # the case the build fuzz found
+    drop = (ida.Builder().metric(1).ef_search(S(kind, 8, 100)).ef_construction(S(kind, 8, 64))
+            .max_batch(S(kind, 1, 0)).tie_policy(ida.TIES_DROP))
+    h = ida.Hnsw.from_ordered_points(pts, drop)
+    assert h.build_stats().tie_overflow == (1 if overflowed else 0)
+    zero, layers = h.into_parts()
+    if not overflowed:                                                              # nothing dropped: the strict graph
+        assert np.array_equal(zero, hs.into_parts()[0])
+    zero2, _ = ida.Hnsw.from_ordered_points(pts, drop).into_parts()
+    assert np.array_equal(zero, zero2)
+    ida.Hnsw.from_parts(pts, zero, layers, drop)                                    # row invariants hold
+    s = ida.Search()
+    got = h.search_batch(q, s)
+    assert s.tie_overflowed() in (True, False)
+    for i in range(len(q)):                                                         # the nearest copies come back
+        c = int(got.count[i])
+        assert c >= 1 and np.all(got.distance[i, : c - 1] <= got.distance[i, 1:c])
+        d0 = float(np.sqrt(np.min(np.sum((pts - q[i]) ** 2, axis=1))))
+        assert abs(float(got.distance[i, 0]) - d0) < 1e-5
+    # data without mass ties is untouched by the policy: byte-identical graph, flag clear
+    pts2 = pc.gen_points(rng, S(kind, 150, 4000), 6)
+    a = ida.Hnsw.from_ordered_points(pts2, ida.Builder().max_batch(1))
+    b = ida.Hnsw.from_ordered_points(pts2, ida.Builder().max_batch(1).tie_policy(ida.TIES_DROP))
+    assert np.array_equal(a.into_parts()[0], b.into_parts()[0]) and b.build_stats().tie_overflow == 0
