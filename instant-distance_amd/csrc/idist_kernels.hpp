@@ -123,7 +123,7 @@ struct SearchArgs {
     uint32_t use_bloom;     // LDS Bloom filter in front of the visited bytes
 };
 
-// LAT = 1: latency variant for narrow batches (see search_layer).
+// LAT: walk mode (kWalkClassic / kWalkLatency / kWalkOverlap, see search_layer).
 template <int NB, int RS, int TAIL, int LAT = 0>
 __global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) {
     IDIST_DYN_SMEM(smem_raw);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) 
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
     Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot], a.use_bloom ? sm.bloom : nullptr,
-                LAT ? kBloomLatLog2Words : kBloomLog2Words};
+                LAT == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
     uint32_t status = 0;
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
     for (;;) {
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
     Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot], a.use_bloom ? sm.bloom : nullptr,
-                LAT ? kBloomLatLog2Words : kBloomLog2Words};
+                LAT == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
     uint32_t status = 0;
     Counters tot{0, 0, 0};
     for (;;) {

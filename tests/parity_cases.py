@@ -11,22 +11,29 @@ import numpy as np
 
 INVALID = 0xFFFFFFFF
 
-# the search kernel has a throughput and a latency variant (chosen by the batch width, IDIST_LATENCY_NQ);
-# both must give the reference's results
-SEARCH_VARIANTS = (("throughput", "0"), ("latency", "4000000000"))
+# the graph walk has three modes (idist_device.hpp: classic / latency / overlap), chosen by the batch width
+# (IDIST_LATENCY_NQ) and IDIST_WALK; all must give the reference's results
+SEARCH_VARIANTS = (("overlap", {"IDIST_LATENCY_NQ": "0"}),
+                   ("latency", {"IDIST_LATENCY_NQ": "4000000000"}),
+                   ("classic", {"IDIST_LATENCY_NQ": "0", "IDIST_WALK": "classic"}))
 
 
 @contextlib.contextmanager
-def search_variant(latency_nq):
-    old = os.environ.get("IDIST_LATENCY_NQ")
-    os.environ["IDIST_LATENCY_NQ"] = latency_nq
+def search_variant(env):
+    if isinstance(env, str):                     # a bare IDIST_LATENCY_NQ value
+        env = {"IDIST_LATENCY_NQ": env}
+    keys = ("IDIST_LATENCY_NQ", "IDIST_WALK")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ.pop(k, None)
+    os.environ.update(env)
     try:
         yield
     finally:
-        if old is None:
-            os.environ.pop("IDIST_LATENCY_NQ", None)
-        else:
-            os.environ["IDIST_LATENCY_NQ"] = old
+        for k in keys:
+            os.environ.pop(k, None)
+            if old[k] is not None:
+                os.environ[k] = old[k]
 
 
 def check_search_result(got, want):
