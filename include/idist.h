@@ -28,7 +28,7 @@
  *                          variant of the graph walk; default 1024, 0 = never
  *   IDIST_WALK=classic     full batches / wide build steps with the classic walk instead of the overlap walk
  *   IDIST_VISITED_TRIES=<n> candidate allocations among which a context's visited array is chosen by timing
- *                          the search kernel (default 4, 1 = take the first)
+ *                          the search kernel (default 6, spaced 12 GB apart: IDIST_VISITED_SPACER_GB; 1 = take the first)
  *   IDIST_BLOOM=0          no LDS Bloom filter in front of the visited bytes
  *   IDIST_BRUTEFORCE=scan|mfma, IDIST_BF_SAMPLE=<n>   force a path of idist_bruteforce / its sample size
  *   IDIST_BUILD_PIPELINE=0 concurrent builds without the two-stream pipeline (a new point then sees all

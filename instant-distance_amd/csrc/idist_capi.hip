@@ -648,11 +648,11 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
 // Where a context's visited array (one byte per point and slot: 4 GB at 1M points) lands in HBM decides ~11 % of the
 // search kernel's time: of ten identical allocations in one process, the same four made every launch slower, on any
 // stream (profiles/probe_r01_visited_placement.jsonl) — an interplay with the index's own placement that a write
-// probe on the array alone does not show.  So the array is chosen among up to IDIST_VISITED_TRIES (default 4)
+// probe on the array alone does not show.  So the array is chosen among up to IDIST_VISITED_TRIES (default 6)
 // candidate allocations by timing the real search kernel on each (2048 stored rows as queries, results discarded);
 // all candidates stay allocated until the choice is made (a freed block would simply be handed out again).
 idist_status place_visited(const idist_index* idx, idist_search_ctx* c, size_t vb) {
-    int tries = 4;
+    int tries = 6;
     if (const char* e = getenv("IDIST_VISITED_TRIES")) tries = std::min(8, std::max(1, atoi(e)));
     size_t freeb = 0, totalb = 0;
     const uint32_t ef = idx->cfg.ef_search;
@@ -673,13 +673,23 @@ idist_status place_visited(const idist_index* idx, idist_search_ctx* c, size_t v
         (void)hipGetLastError();
         return IDIST_OK;                                   // no calibration, keep the first allocation
     }
+    // Consecutive allocations tend to share their class (the classes come in runs of several 4-GB blocks), so the
+    // candidates are spread out: a spacer of `IDIST_VISITED_SPACER_GB` (default 12) is held between two of them
+    // while they are allocated, memory permitting.
+    size_t spacer = (size_t)12 << 30;
+    if (const char* e = getenv("IDIST_VISITED_SPACER_GB")) spacer = (size_t)atoll(e) << 30;
+    void* spacers[8] = {nullptr};
     for (; have < tries; have++) {
+        if (spacer && hipMemGetInfo(&freeb, &totalb) == hipSuccess && freeb > 2 * (spacer + vb) + ((size_t)16 << 30)) {
+            if (hipMalloc(&spacers[have], spacer) != hipSuccess) { spacers[have] = nullptr; (void)hipGetLastError(); }
+        }
         if (hipMalloc((void**)&cand[have], vb) != hipSuccess || hipMemset(cand[have], 0, vb) != hipSuccess) {
             hipFree(cand[have]);
             (void)hipGetLastError();
             break;
         }
     }
+    for (int t = 0; t < 8; t++) hipFree(spacers[t]);
     int pick = 0;
     float best = 1e30f;
     for (int t = 0; t < have; t++) {
