@@ -98,6 +98,7 @@ SYMBOLS = {
     "idist_index_get_info": (C.c_int32, [_vp, C.POINTER(IndexInfo)]),
     "idist_index_device_buffers": (C.c_int32, [_vp, C.POINTER(DeviceBuffers)]),
     "idist_index_set_ef_search": (C.c_int32, [_vp, C.c_uint32]),
+    "idist_index_rehome": (C.c_int32, [_vp]),
     "idist_index_free": (None, [_vp]),
     "idist_search_ctx_new": (C.c_int32, [_vp, C.c_uint32, C.POINTER(_vp)]),
     "idist_search_ctx_free": (None, [_vp]),

@@ -383,6 +383,10 @@ class Hnsw:
         _lib().check(_lib().idist_index_build_stats(self._h, C.byref(st)))
         return st
 
+    def rehome(self):
+        """Move the index's device buffers into fresh allocations (placement in HBM, see idist_index_rehome)."""
+        _lib().check(_lib().idist_index_rehome(self._h))
+
     def set_ef_search(self, ef: int):
         _lib().check(_lib().idist_index_set_ef_search(self._h, int(ef)))
         self._ef_search = int(ef)

@@ -942,6 +942,27 @@ idist_status idist_index_set_ef_search(idist_index* idx, uint32_t ef_search) {
     return IDIST_OK;
 }
 
+idist_status idist_index_rehome(idist_index* idx) {
+    if (!idx) return fail(IDIST_ERR_INVALID_ARG, "idx is null");
+    HIPCHK(hipSetDevice(idx->device));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t pb = std::max<size_t>((size_t)idx->n * idx->L.stride * 4, 256), zb = std::max<size_t>((size_t)idx->n * IDIST_M2 * 4, 256),
+                 ub = std::max<size_t>(idx->upper_rows * IDIST_M * 4, 256);
+    float* np_ = nullptr;
+    uint32_t *nz = nullptr, *nu = nullptr;
+    if (hipMalloc((void**)&np_, pb) != hipSuccess || hipMalloc((void**)&nz, zb) != hipSuccess || hipMalloc((void**)&nu, ub) != hipSuccess ||
+        hipMemcpy(np_, idx->d_points, pb, hipMemcpyDeviceToDevice) != hipSuccess ||
+        hipMemcpy(nz, idx->d_zero, zb, hipMemcpyDeviceToDevice) != hipSuccess ||
+        hipMemcpy(nu, idx->d_upper, ub, hipMemcpyDeviceToDevice) != hipSuccess) {
+        hipFree(np_); hipFree(nz); hipFree(nu);
+        return fail(IDIST_ERR_HIP, "rehome: %s", hipGetErrorString(hipGetLastError()));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    hipFree(idx->d_points); hipFree(idx->d_zero); hipFree(idx->d_upper);
+    idx->d_points = np_; idx->d_zero = nz; idx->d_upper = nu;
+    return IDIST_OK;
+}
+
 void idist_index_free(idist_index* idx) {
     if (!idx) return;
     hipSetDevice(idx->device);
