@@ -94,6 +94,9 @@ typedef struct idist_config {
                                    DROP: keep the 64 smallest (distance, pid) ties, never expand the
                                    others, and go on — deterministic, flagged in idist_build_stats /
                                    idist_search_ctx_tie_overflowed, no longer bit-identical on such data. */
+    uint32_t tie_capacity;      /* size of that tie region, 0 = 64 (the default), at most 4096.  It lives in LDS
+                                   next to `nearest` (8 B per entry): raising it keeps such data bit-identical
+                                   to the reference at the price of fewer resident waves per CU. */
 } idist_config;
 
 typedef struct idist_index idist_index;

@@ -45,6 +45,7 @@ class Config(C.Structure):
         ("metric", C.c_int32),
         ("max_batch", C.c_uint32),
         ("tie_policy", C.c_int32),
+        ("tie_capacity", C.c_uint32),
     ]
 
 

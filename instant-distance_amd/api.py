@@ -57,6 +57,7 @@ class Builder:
         self._device = 0
         self._progress = None
         self._tie_policy = TIES_STRICT
+        self._tie_capacity = 0
 
     @classmethod
     def default(cls) -> "Builder":
@@ -104,6 +105,12 @@ class Builder:
         self._tie_policy = int(policy)
         return self
 
+    def tie_capacity(self, n: int) -> "Builder":
+        """Entries of the tie region behind `nearest` (0 = 64, at most 4096): raise it for data with masses of
+        exactly equal distances (dense integer grids) to stay bit-identical to the reference there."""
+        self._tie_capacity = int(n)
+        return self
+
     def max_batch(self, k: int) -> "Builder":
         """1 = strictly sequential insertion (deterministic contract); 0 = default."""
         self._max_batch = int(k)
@@ -128,6 +135,7 @@ class Builder:
         c.metric = self._metric
         c.max_batch = self._max_batch
         c.tie_policy = self._tie_policy
+        c.tie_capacity = self._tie_capacity
         return c
 
     def build(self, points, values: Sequence[Any]) -> "HnswMap":

@@ -109,6 +109,7 @@ idist_status validate_config(const idist_config* cfg, bool for_build) {
         return fail(IDIST_ERR_INVALID_ARG, "unknown metric %d", cfg->metric);
     if (cfg->tie_policy != IDIST_TIES_STRICT && cfg->tie_policy != IDIST_TIES_DROP)
         return fail(IDIST_ERR_INVALID_ARG, "unknown tie_policy %d", cfg->tie_policy);
+    if (cfg->tie_capacity > 4096) return fail(IDIST_ERR_INVALID_ARG, "tie_capacity %u > 4096", cfg->tie_capacity);
     if (for_build) {
         if (cfg->ef_construction == 0 || cfg->ef_construction > IDIST_MAX_EF)
             return fail(IDIST_ERR_INVALID_ARG, "ef_construction %u out of [1,%u]", cfg->ef_construction, IDIST_MAX_EF);
@@ -291,11 +292,14 @@ bool use_bloom_filter() {
     return !(e && e[0] == '0');
 }
 
+thread_local uint32_t g_tie_cap_msg = kTieCap;
+uint32_t tie_capacity(const idist_config& cfg) { return g_tie_cap_msg = cfg.tie_capacity ? cfg.tie_capacity : (uint32_t)kTieCap; }
+
 idist_status device_status_to_code(uint32_t st, int32_t tie_policy) {
     if (st & kStBadRow) return fail(IDIST_ERR_BAD_GRAPH, "device met an adjacency id >= n");
     if ((st & kStTieOverflow) && tie_policy == IDIST_TIES_STRICT)
         return fail(IDIST_ERR_TIE_OVERFLOW, "more than %d live equidistant candidates beyond ef "
-                    "(idist_config.tie_policy = IDIST_TIES_DROP keeps the nearest %d and goes on)", kTieCap, kTieCap);
+                    "(raise idist_config.tie_capacity, or tie_policy = IDIST_TIES_DROP keeps the nearest ones and goes on)", (int)g_tie_cap_msg);
     if (st & kStGuard) return fail(IDIST_ERR_INTERNAL, "device-side loop guard tripped");
     return IDIST_OK;
 }
@@ -312,7 +316,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     const uint32_t slots_max = default_slots(ix);
     const uint32_t slots = std::min(cap, slots_max);
     const size_t vis_stride = ((size_t)n + 255) & ~(size_t)255;
-    const uint32_t wcap = cfg.ef_construction + 64 + kTieCap + 64;
+    const uint32_t tie_cap = tie_capacity(cfg);
+    const uint32_t wcap = cfg.ef_construction + 64 + tie_cap + 64;
     const size_t smem = smem_bytes(ix->L.stride, wcap, true);
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave (> 64 KiB)", smem);
     // steps too narrow to fill the chip (the early graph, max_batch = 1) run the latency variant of the descent
@@ -440,6 +445,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     a.wbuf = d_wbuf;
     a.wcount = d_wcount;
     a.rt2 = rt2;
+    a.tie_cap = tie_cap;
     if (const char* e = getenv("IDIST_BUILD_CHUNK")) a.chunk = (uint32_t)atoi(e);
     const size_t smemF = smem_bytes_update_fast(ix->L.stride);
     const bool classic = classic_walk();
@@ -604,7 +610,8 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     a.queries = d_q;
     a.nq = nq;
     a.ef = ef;
-    a.wcap = ef + 64 + kTieCap + 8;
+    a.tie_cap = tie_capacity(ix->cfg);
+    a.wcap = ef + 64 + a.tie_cap + 8;
     a.out_pid = d_pid;
     a.out_dist = d_dist;
     a.out_count = d_cnt;
@@ -741,6 +748,7 @@ idist_status idist_default_config(idist_config* cfg) {   // core/lib.rs:101-128
     cfg->metric = IDIST_METRIC_L2SQ;
     cfg->max_batch = 0;
     cfg->tie_policy = IDIST_TIES_STRICT;
+    cfg->tie_capacity = 0;
     return IDIST_OK;
 }
 

@@ -37,7 +37,7 @@ constexpr int kM = 32;
 constexpr int kM2 = 64;
 constexpr uint64_t kFlag = 1ull << 63;   // entry already expanded
 constexpr uint64_t kKeyMask = ~kFlag;
-constexpr int kTieCap = 64;              // live equidistant candidates kept beyond ef
+constexpr int kTieCap = 64;              // live equidistant candidates kept beyond ef (default; idist_config.tie_capacity)
 constexpr uint32_t kNanBits = 0x7fc00000u;
 constexpr uint64_t kMaxKey = 0x7fffffffffffffffull;
 
@@ -310,6 +310,7 @@ struct WState {
     int ef;
     int cursor;      // lower bound of the first un-expanded entry
     uint32_t status;
+    int tie_cap = kTieCap;   // capacity of the tie region behind W[ef)
 };
 
 // number of entries with (masked) key < k  == Vec::binary_search Err(idx), core/lib.rs:712
@@ -388,7 +389,7 @@ __device__ __forceinline__ void w_truncate(WState& st) {
         wave_sync();
         out += __popcll(m);
     }
-    if (out - st.ef > kTieCap) { st.status |= kStTieOverflow; out = st.ef + kTieCap; }
+    if (out - st.ef > st.tie_cap) { st.status |= kStTieOverflow; out = st.ef + st.tie_cap; }
     st.plen = out;
     if (st.cursor > st.ef) st.cursor = st.ef;
 }

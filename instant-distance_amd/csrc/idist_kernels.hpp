@@ -121,6 +121,7 @@ struct SearchArgs {
     uint32_t* next;         // work queue head
     uint32_t* status;
     uint32_t use_bloom;     // LDS Bloom filter in front of the visited bytes
+    uint32_t tie_cap;       // capacity of the tie region (idist_config.tie_capacity)
 };
 
 // LAT: walk mode (kWalkClassic / kWalkLatency / kWalkOverlap, see search_layer).
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) 
         for (uint32_t e = lane; e < ix.dim; e += 64) sm.q[blocked_pos(e, nb)] = qsrc[e];
         wave_sync();
 
-        WState st{sm.W, 0, 1, 0, 0u};
+        WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
         Counters ctr{0, 0, 0};
         visited_clear(vis);                                            // search.reset(), :357
         push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr);  // :364
@@ -316,6 +317,7 @@ struct BuildArgs {
     uint32_t rt;                // step B2: selected rows kept in the LDS tile
     uint32_t rt2;               // step A2: same for the new point's own selection
     uint32_t chunk;             // step B: items per dequeue, 0 = by load (IDIST_BUILD_CHUNK, test knob)
+    uint32_t tie_cap;           // capacity of the tie region of the descent (idist_config.tie_capacity)
     uint32_t* queue;            // work queue heads: [0] step A, [1] step B, [3] step B2, [4] step A2 ([2] = n_slow)
     unsigned long long* stats;  // [8] n_dist n_exp0 n_expU n_heur_dist n_heur_rows n_updates
     uint32_t* status;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
             *reinterpret_cast<float4*>(sm.q + o) = *reinterpret_cast<const float4*>(prow + o);
         wave_sync();
 
-        WState st{sm.W, 0, 1, 0, 0u};
+        WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
         uint64_t* dlog = a.dlog + (size_t)item * kDlogCap;
         visited_clear(vis);                                           // search.reset(), :443
         push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, dlog);  // :444

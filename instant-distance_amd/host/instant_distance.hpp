@@ -129,6 +129,7 @@ public:
     // engine knobs (not in the reference)
     Builder max_batch(uint32_t k) && { cfg_.max_batch = k; return std::move(*this); }
     Builder tie_policy(int32_t p) && { cfg_.tie_policy = p; return std::move(*this); }   // IDIST_TIES_STRICT / IDIST_TIES_DROP
+    Builder tie_capacity(uint32_t n) && { cfg_.tie_capacity = n; return std::move(*this); }
     Builder device(int d) && { device_ = d; return std::move(*this); }
 
     template <class P, class V> HnswMap<P, V> build(std::vector<P> points, std::vector<V> values) && {         // :78-80

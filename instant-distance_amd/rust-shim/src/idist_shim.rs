@@ -27,6 +27,7 @@ pub struct IdistConfig {
     metric: i32,
     max_batch: u32,
     tie_policy: i32,   // 0 = strict (IDIST_ERR_TIE_OVERFLOW), 1 = drop: see include/idist.h
+    tie_capacity: u32, // 0 = 64
 }
 #[repr(C)] struct IdistIndex { _p: [u8; 0] }
 #[repr(C)] struct IdistSearchCtx { _p: [u8; 0] }

@@ -72,6 +72,11 @@ def test_search_parity_heavy_ties(eng, oracle):
             assert e.status == 6
             continue
         pc.check_search_result(got, want)
+    # with a larger tie region (idist_config.tie_capacity) the same data must match the reference, no error allowed
+    hb = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().metric(1).ef_search(20).tie_capacity(2048))
+    for _, lat in pc.SEARCH_VARIANTS:
+        with pc.search_variant(lat):
+            pc.check_search_result(hb.search_batch(q, ida.Search(), counters=True), want)
 
 
 def test_duplicate_points(eng, oracle):
@@ -576,6 +581,12 @@ def test_tie_policy(eng, oracle):
         assert c >= 1 and np.all(got.distance[i, : c - 1] <= got.distance[i, 1:c])
         d0 = float(np.sqrt(np.min(np.sum((pts - q[i]) ** 2, axis=1))))
         assert abs(float(got.distance[i, 0]) - d0) < 1e-5
+    # a larger tie region instead: strict, and the search agrees with the oracle on the oracle's graph bit for bit
+    cfg = oracle.default_config(metric=1, ef_search=S(kind, 8, 100), ef_construction=S(kind, 8, 64))
+    oix = oracle.Index.build(pts, cfg, threads=4)
+    big = ida.Builder().metric(1).ef_search(S(kind, 8, 100)).tie_capacity(4096)
+    hb = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, big)
+    pc.check_search_result(hb.search_batch(q, ida.Search(), counters=True), oix.search(q))
     # data without mass ties is untouched by the policy: byte-identical graph, flag clear
     pts2 = pc.gen_points(rng, S(kind, 150, 4000), 6)
     a = ida.Hnsw.from_ordered_points(pts2, ida.Builder().max_batch(1))
