@@ -34,6 +34,7 @@
  *   IDIST_BUILD_PIPELINE=0 concurrent builds without the two-stream pipeline (a new point then sees all
  *                          points up to the previous step instead of the one before; graphs differ, quality
  *                          does not)
+ *   IDIST_BUILD_CHECK=1    self-check at the end of a pipelined build: both copies of the zero layer must agree
  *   IDIST_BUILD_A_WAVES=<n> descent waves per CU in the pipelined schedule (default 10)
  *   IDIST_BUILD_RT, IDIST_BUILD_RT2, IDIST_BUILD_NO_FAST, IDIST_BUILD_CHUNK  build tile sizes / route every
  *                          neighbour update through the from-scratch kernel / updates per work-queue dequeue

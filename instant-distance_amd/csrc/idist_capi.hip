@@ -553,6 +553,21 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     }
     if (pipe) {
         if (n_batches) BCHK(hipStreamWaitEvent(s1, evS[n_batches & 1u], 0));
+        if (getenv("IDIST_BUILD_CHECK")) {
+            // self-check: carry the last step over as well; now the two copies must agree on every row, or some
+            // step's carry-over missed a row
+            const int par = (int)(n_batches & 1u);
+            IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s1, zbuf[par], zbuf[par ^ 1], a.touched, smallS, prev_start, prev_count);
+            BCHK(hipMemsetAsync(d_small + 40, 0, 4, s1));
+            IDIST_LAUNCH(count_row_mismatch_kernel, 1024, 256, 0, s1, zbuf[0], zbuf[1], n, d_small + 40);
+            uint32_t bad = 0;
+            BCHK(hipStreamSynchronize(s1));
+            BCHK(hipMemcpy(&bad, d_small + 40, 4, hipMemcpyDeviceToHost));
+            if (bad) {
+                release();
+                return fail(IDIST_ERR_INTERNAL, "pipelined build: the two copies of the zero layer differ on %u rows", bad);
+            }
+        }
         if (n_batches & 1u) std::swap(ix->d_zero, d_zero2);              // the final state lives in copy (last step)&1
     }
     BCHK(hipEventRecord(e1, stream));

@@ -45,6 +45,16 @@ __global__ __launch_bounds__(64) void copy_rows_kernel(const uint32_t* __restric
     }
 }
 
+// Self-check of the pipelined build (IDIST_BUILD_CHECK): counts the zero rows on which the two copies disagree
+__global__ void count_row_mismatch_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t rows,
+                                          uint32_t* n_bad) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+        bool bad = false;
+        for (int i = 0; i < kM2; i++) bad = bad || a[(size_t)r * kM2 + i] != b[(size_t)r * kM2 + i];
+        if (bad) atomicAdd(n_bad, 1u);
+    }
+}
+
 // Builder::progress: one thread publishes {done, layer} to pinned host memory after a build step
 __global__ void progress_kernel(volatile unsigned long long* slot, unsigned long long done, unsigned long long layer) {
     slot[0] = done;

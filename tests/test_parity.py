@@ -180,6 +180,7 @@ def test_build_batched(eng, oracle, monkeypatch, pipeline):
     # both schedules of a concurrent build: pipelined (descents of step k+1 overlap the updates of step k) and not
     ida, kind = eng
     monkeypatch.setenv("IDIST_BUILD_PIPELINE", pipeline)
+    monkeypatch.setenv("IDIST_BUILD_CHECK", "1")      # pipelined: the two copies of the zero layer must agree at the end
     rec = pc.check_build_batched(ida, oracle, n=S(kind, 220, 30000), dim=S(kind, 4, 32), max_batch=S(kind, 4, 0),
                                  nq=S(kind, 20, 500))
     assert rec >= 0.95
@@ -201,6 +202,7 @@ def test_build_batched_is_schedule_independent(eng, oracle, monkeypatch):
         envs += [{"IDIST_BUILD_CHUNK": "1"}, {"IDIST_BUILD_CHUNK": "16"}, {"IDIST_LATENCY_NQ": "4000000000"}]
     for env in envs:
         with monkeypatch.context() as m:
+            m.setenv("IDIST_BUILD_CHECK", "1")
             for k_, v in env.items():
                 m.setenv(k_, v)
             zero, layers = ida.Hnsw.from_ordered_points(pts, b).into_parts()
