@@ -726,14 +726,15 @@ idist_status place_visited(const idist_index* idx, idist_search_ctx* c, size_t v
         if (getenv("IDIST_DEBUG_PTRS")) fprintf(stderr, "[idist] visited candidate %d: %p calibration %.3f ms\n", t, (void*)cand[t], ms);
         if (ms < best) { best = ms; pick = t; }
     }
-    hipStreamSynchronize(c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
     for (int t = 0; t < have; t++)
         if (t != pick) hipFree(cand[t]);
     c->d_visited = cand[pick];
     c->n_launch = 0;                                       // the calibration launches are not the caller's
-    uint32_t zero2[2] = {0, 0};
-    hipMemcpy(c->d_next, zero2, 8, hipMemcpyHostToDevice); // queue head and device status of the throw-away searches
+    const uint32_t zero2[2] = {0, 0};                      // queue head and device status of the throw-away searches
+    if (e == hipSuccess) e = hipMemcpy(c->d_next, zero2, 8, hipMemcpyHostToDevice);
     release();
+    if (e != hipSuccess) return fail(IDIST_ERR_HIP, "visited placement: %s", hipGetErrorString(e));
     return IDIST_OK;
 }
 
@@ -1021,7 +1022,7 @@ idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_
         if ((e = hipEventCreate(&c->ev0[i])) != hipSuccess) return bail(e);
         if ((e = hipEventCreate(&c->ev1[i])) != hipSuccess) return bail(e);
     }
-    CHK(place_visited(idx, c, vb));
+    if (place_visited(idx, c, vb) != IDIST_OK) { idist_search_ctx_free(c); return IDIST_ERR_HIP; }
     // the scratch above was cleared on the null stream; a caller's non-blocking stream would not wait for it
     if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(e);
     *out = c;
