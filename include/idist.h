@@ -96,8 +96,12 @@ typedef struct idist_config {
                                    others, and go on — deterministic, flagged in idist_build_stats /
                                    idist_search_ctx_tie_overflowed, no longer bit-identical on such data. */
     uint32_t tie_capacity;      /* size of that tie region, 0 = 64 (the default), at most 4096.  It lives in LDS
-                                   next to `nearest` (8 B per entry): raising it keeps such data bit-identical
-                                   to the reference at the price of fewer resident waves per CU. */
+                                   next to `nearest` (8 B per entry): a larger one keeps such data bit-identical
+                                   to the reference at the price of fewer resident waves per CU.  STRICT enlarges
+                                   it by itself: a build that overflows is repeated with 8x the region, a
+                                   host-pointer search batch with 4x (the device-pointer variant reports the
+                                   overflow through idist_search_ctx_status and uses the larger region from the
+                                   next launch on); only beyond 4096 entries is the error final. */
 } idist_config;
 
 typedef struct idist_index idist_index;
@@ -111,6 +115,7 @@ typedef struct idist_index_info {
     int32_t metric;
     int32_t device;
     uint32_t layer_len[IDIST_MAX_LAYERS]; /* layer_len[l-1] = rows of layers[l-1], l = 1..n_upper */
+    uint32_t tie_capacity;      /* the tie region the build ended up using (see idist_config.tie_capacity) */
 } idist_index_info;
 
 /* Raw device views (for RCCL replication by the host: torch.distributed / ncclBroadcast). */

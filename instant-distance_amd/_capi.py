@@ -54,6 +54,7 @@ class IndexInfo(C.Structure):
         ("n", C.c_uint32), ("dim", C.c_uint32), ("row_stride", C.c_uint32), ("n_upper", C.c_uint32),
         ("ef_search", C.c_uint32), ("metric", C.c_int32), ("device", C.c_int32),
         ("layer_len", C.c_uint32 * MAX_LAYERS),
+        ("tie_capacity", C.c_uint32),
     ]
 
 

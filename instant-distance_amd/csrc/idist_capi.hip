@@ -180,6 +180,7 @@ struct idist_search_ctx {
     uint32_t* d_ctr = nullptr;
     size_t cap_q = 0, cap_out = 0, cap_nq = 0;
     bool tie_overflowed = false;
+    uint32_t tie_cap = 0;          // tie capacity this context escalated to (0 = the index's)
 };
 
 namespace {
@@ -607,15 +608,21 @@ idist_status build_common(const void* points, bool on_device, uint32_t n, uint32
         nl = layer_sizes(n, cfg->ml, cum, IDIST_MAX_LAYERS);
         if (nl == 0) return fail(IDIST_ERR_INVALID_ARG, "ml = %g yields more than %u layers", (double)cfg->ml, IDIST_MAX_LAYERS);
     }
-    idist_index* ix = nullptr;
-    CHK(index_alloc(n, dim, cfg, cum + 1, n ? nl - 1 : 0, device, &ix));
-    idist_status s = on_device ? load_points_device(ix, (const float*)points) : load_points_host(ix, (const float*)points);
     idist_progress* prog = g_watch;
     g_watch = nullptr;
-    if (s == IDIST_OK) s = run_build(ix, prog);
-    if (s != IDIST_OK) { idist_index_free(ix); return s; }
-    *out = ix;
-    return IDIST_OK;
+    idist_config c = *cfg;
+    for (;;) {
+        idist_index* ix = nullptr;
+        CHK(index_alloc(n, dim, &c, cum + 1, n ? nl - 1 : 0, device, &ix));
+        idist_status s = on_device ? load_points_device(ix, (const float*)points) : load_points_host(ix, (const float*)points);
+        if (s == IDIST_OK) s = run_build(ix, prog);
+        if (s == IDIST_OK) { *out = ix; return IDIST_OK; }
+        idist_index_free(ix);
+        // strict ties: the descent's tie region was too small -> build again with a larger one (x8, at most 4096)
+        const uint32_t cap = tie_capacity(c);
+        if (s != IDIST_ERR_TIE_OVERFLOW || cap >= 4096u) return s;
+        c.tie_capacity = std::min<uint32_t>(4096u, cap * 8u);
+    }
 }
 
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
@@ -625,7 +632,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     a.queries = d_q;
     a.nq = nq;
     a.ef = ef;
-    a.tie_cap = tie_capacity(ix->cfg);
+    a.tie_cap = std::max(tie_capacity(ix->cfg), ctx->tie_cap);
     a.wcap = ef + 64 + a.tie_cap + 8;
     a.out_pid = d_pid;
     a.out_dist = d_dist;
@@ -944,6 +951,7 @@ idist_status idist_index_get_info(const idist_index* idx, idist_index_info* out)
     out->ef_search = idx->cfg.ef_search;
     out->metric = idx->cfg.metric;
     out->device = idx->device;
+    out->tie_capacity = tie_capacity(idx->cfg);
     for (uint32_t l = 0; l < idx->n_upper; l++) out->layer_len[l] = idx->layer_len[l];
     return IDIST_OK;
 }
@@ -1070,7 +1078,14 @@ idist_status idist_search_ctx_status(idist_search_ctx* ctx) {
     uint32_t st = 0;
     HIPCHK(hipMemcpy(&st, ctx->d_next + 1, 4, hipMemcpyDeviceToHost));
     if (st) HIPCHK(hipMemset(ctx->d_next + 1, 0, 4));
-    if (st & kStTieOverflow) ctx->tie_overflowed = true;
+    if (st & kStTieOverflow) {
+        ctx->tie_overflowed = true;
+        // strict: later launches of this context get a larger tie region (x4, at most 4096 entries, LDS permitting)
+        const uint32_t cap = std::max(tie_capacity(ctx->idx->cfg), ctx->tie_cap), next = std::min<uint32_t>(4096u, cap * 4u);
+        if (ctx->idx->cfg.tie_policy == IDIST_TIES_STRICT && next > cap &&
+            smem_bytes(ctx->idx->L.stride, ctx->idx->cfg.ef_search + 64 + next + 8, false) <= 64 * 1024)
+            ctx->tie_cap = next;
+    }
     return device_status_to_code(st, ctx->idx->cfg.tie_policy);
 }
 
@@ -1132,14 +1147,21 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
         ctx->cap_nq = nq;
     }
     HIPCHK(hipMemcpyAsync(ctx->d_q, queries, qb, hipMemcpyHostToDevice, ctx->stream));
-    CHK(launch_search(idx, ctx, ctx->d_q, nq, ctx->d_pid, ctx->d_dist, ctx->d_cnt, out_counters ? ctx->d_ctr : nullptr,
-                      ctx->stream));
-    HIPCHK(hipMemcpyAsync(out_pid, ctx->d_pid, ob, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(out_dist, ctx->d_dist, ob, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(out_count, ctx->d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_counters) HIPCHK(hipMemcpyAsync(out_counters, ctx->d_ctr, (size_t)nq * 12, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return idist_search_ctx_status(ctx);
+    for (;;) {
+        CHK(launch_search(idx, ctx, ctx->d_q, nq, ctx->d_pid, ctx->d_dist, ctx->d_cnt, out_counters ? ctx->d_ctr : nullptr,
+                          ctx->stream));
+        HIPCHK(hipMemcpyAsync(out_pid, ctx->d_pid, ob, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(out_dist, ctx->d_dist, ob, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(out_count, ctx->d_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_counters) HIPCHK(hipMemcpyAsync(out_counters, ctx->d_ctr, (size_t)nq * 12, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        // strict ties: the tie region was too small -> idist_search_ctx_status enlarged it for this context; the
+        // batch is simply searched again (queries are independent and the results are overwritten)
+        const uint32_t cap_before = std::max(tie_capacity(idx->cfg), ctx->tie_cap);
+        const idist_status s = idist_search_ctx_status(ctx);
+        if (s == IDIST_ERR_TIE_OVERFLOW && std::max(tie_capacity(idx->cfg), ctx->tie_cap) > cap_before) continue;
+        return s;
+    }
 }
 
 idist_status idist_distance_batch(const idist_index* idx, const float* queries, uint32_t nq, const uint32_t* ids,

@@ -549,47 +549,45 @@ def test_concurrent_build_invariants_emulated(engine_loader, oracle):
 
 
 def test_tie_policy(eng, oracle):
-    """> 64 un-expanded candidates exactly at the furthest distance (mass duplicates): STRICT reports
-    IDIST_ERR_TIE_OVERFLOW, DROP builds and searches a valid graph deterministically and flags the event."""
+    """> 64 un-expanded candidates exactly at the furthest distance (dense integer grids).  STRICT (default) enlarges
+    the tie region by itself — the build is repeated, a host-pointer search batch is searched again — and stays
+    bit-identical to the reference; DROP keeps the default region, goes on deterministically and flags the event."""
     ida, kind = eng
     rng = np.random.default_rng(3000002)
     n = S(kind, 420, 41640)
-    pts = pc.gen_points(rng, n, S(kind, 3, 5), "grid")               # dense integer grid: masses of equal distances
+    pts = pc.gen_points(rng, n, S(kind, 3, 5), "grid")               # the case the concurrent-build fuzz found
     q = pts[: S(kind, 3, 20)] + np.float32(0.25)
-    strict = (ida.Builder().metric(1).ef_search(S(kind, 8, 100)).ef_construction(S(kind, 8, 64))
-              .max_batch(S(kind, 1, 0)))
-    overflowed = False
-    try:
-        hs = ida.Hnsw.from_ordered_points(pts, strict)
-    except ida.IdistError as e:
-        assert e.status == 6
-        overflowed = True
+    base = lambda: (ida.Builder().metric(1).ef_search(S(kind, 8, 100)).ef_construction(S(kind, 8, 64))   # noqa: E731
+                    .max_batch(S(kind, 1, 0)))
+    hs = ida.Hnsw.from_ordered_points(pts, base())                    # strict: succeeds, with a larger region if needed
+    assert hs.build_stats().tie_overflow == 0
+    escalated = hs.info().tie_capacity > 64
     if kind == "gpu":
-        assert overflowed                                                           # the case the build fuzz found
-    drop = (ida.Builder().metric(1).ef_search(S(kind, 8, 100)).ef_construction(S(kind, 8, 64))
-            .max_batch(S(kind, 1, 0)).tie_policy(ida.TIES_DROP))
-    h = ida.Hnsw.from_ordered_points(pts, drop)
-    assert h.build_stats().tie_overflow == (1 if overflowed else 0)
+        assert escalated                                              # 64 ties are not enough for this data
+    h = ida.Hnsw.from_ordered_points(pts, base().tie_policy(ida.TIES_DROP))
+    assert h.info().tie_capacity == 64 and h.build_stats().tie_overflow == (1 if escalated else 0)
     zero, layers = h.into_parts()
-    if not overflowed:                                                              # nothing dropped: the strict graph
+    if not escalated:                                                 # nothing dropped: the strict graph
         assert np.array_equal(zero, hs.into_parts()[0])
-    zero2, _ = ida.Hnsw.from_ordered_points(pts, drop).into_parts()
+    zero2, _ = ida.Hnsw.from_ordered_points(pts, base().tie_policy(ida.TIES_DROP)).into_parts()
     assert np.array_equal(zero, zero2)
-    ida.Hnsw.from_parts(pts, zero, layers, drop)                                    # row invariants hold
+    ida.Hnsw.from_parts(pts, zero, layers, base().tie_policy(ida.TIES_DROP))        # row invariants hold
     s = ida.Search()
     got = h.search_batch(q, s)
     assert s.tie_overflowed() in (True, False)
-    for i in range(len(q)):                                                         # the nearest copies come back
+    for i in range(len(q)):                                                         # the nearest points come back
         c = int(got.count[i])
         assert c >= 1 and np.all(got.distance[i, : c - 1] <= got.distance[i, 1:c])
         d0 = float(np.sqrt(np.min(np.sum((pts - q[i]) ** 2, axis=1))))
         assert abs(float(got.distance[i, 0]) - d0) < 1e-5
-    # a larger tie region instead: strict, and the search agrees with the oracle on the oracle's graph bit for bit
+    # strict search on the oracle's graph: default region first, enlarged on demand, bit-identical to the oracle
     cfg = oracle.default_config(metric=1, ef_search=S(kind, 8, 100), ef_construction=S(kind, 8, 64))
     oix = oracle.Index.build(pts, cfg, threads=4)
-    big = ida.Builder().metric(1).ef_search(S(kind, 8, 100)).tie_capacity(4096)
-    hb = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, big)
+    hb = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().metric(1).ef_search(S(kind, 8, 100)))
     pc.check_search_result(hb.search_batch(q, ida.Search(), counters=True), oix.search(q))
+    # ... and with the region requested up front
+    hb2 = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().metric(1).ef_search(S(kind, 8, 100)).tie_capacity(4096))
+    pc.check_search_result(hb2.search_batch(q, ida.Search(), counters=True), oix.search(q))
     # data without mass ties is untouched by the policy: byte-identical graph, flag clear
     pts2 = pc.gen_points(rng, S(kind, 150, 4000), 6)
     a = ida.Hnsw.from_ordered_points(pts2, ida.Builder().max_batch(1))
@@ -612,3 +610,34 @@ def test_index_rehome_keeps_results(eng, oracle):
         assert np.array_equal(a.counters, b.counters)
     z0, l0 = h.into_parts()
     assert np.array_equal(z0, oix.zero) and all(np.array_equal(x, y) for x, y in zip(l0, oix.layers))
+
+
+def test_strict_ties_enlarge_the_region_on_demand(eng, oracle):
+    """The escalation machinery on data small enough for the oracle: with a deliberately tiny tie region (1 entry)
+    integer-grid data overflows it at once; STRICT must still end with the reference's results (search batch searched
+    again with 4x the region, build repeated with 8x), DROP must flag the overflow."""
+    ida, kind = eng
+    rng = np.random.default_rng(17)
+    n, ef = S(kind, 260, 6000), S(kind, 12, 60)
+    pts = rng.integers(0, 3, size=(n, 3)).astype(np.float32)
+    q = rng.integers(0, 3, size=(S(kind, 12, 200), 3)).astype(np.float32) + np.float32(0.5)   # cell centres: many equal distances
+    cfg = oracle.default_config(metric=1, ef_search=ef, ef_construction=ef)
+    oix = oracle.Index.build(pts, cfg)
+    want = oix.search(q)
+    tiny = lambda: ida.Builder().metric(1).ef_search(ef).ef_construction(ef).max_batch(1).tie_capacity(1)   # noqa: E731
+    # the data does overflow a 1-entry region
+    hd = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, tiny().tie_policy(ida.TIES_DROP))
+    sd = ida.Search()
+    hd.search_batch(q, sd)
+    assert sd.tie_overflowed()
+    # strict search: same index config, the context enlarges its region until the batch goes through
+    hs = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, tiny())
+    for _, lat in pc.SEARCH_VARIANTS:
+        with pc.search_variant(lat):
+            pc.check_search_result(hs.search_batch(q, ida.Search(), counters=True), want)
+    # strict build: repeated with a larger region, byte-identical to the oracle in the end
+    hb = ida.Hnsw.from_ordered_points(pts, tiny())
+    assert hb.info().tie_capacity > 1 and hb.build_stats().tie_overflow == 0
+    zero, layers = hb.into_parts()
+    assert np.array_equal(zero, oix.zero) and all(np.array_equal(x, y) for x, y in zip(layers, oix.layers))
+    assert ida.Hnsw.from_ordered_points(pts, tiny().tie_policy(ida.TIES_DROP)).build_stats().tie_overflow == 1
