@@ -199,9 +199,10 @@ idist_status idist_index_get_info(const idist_index* idx, idist_index_info* out)
 idist_status idist_index_device_buffers(const idist_index* idx, idist_device_buffers* out);
 /* Hnsw.ef_search is a field of the index (core/lib.rs:195); bench sweeps change it. */
 idist_status idist_index_set_ef_search(idist_index* idx, uint32_t ef_search);
-/* Moves the index's device buffers (points, zero, upper) into fresh allocations.  Where a buffer lands in HBM
- * moves the search kernel's time by ~10 %; a build ends with this step choosing among candidate
- * placements, and a caller may repeat it.  No search may be in flight on the index; contexts stay valid. */
+/* Moves the index's device buffers (points, zero, upper) into fresh allocations.  Where the index and a context's
+ * visited array land in HBM relative to each other moves the search kernel's time by ~10 %;
+ * idist_search_ctx_new chooses the visited array against the index as it is placed at that moment, so call this
+ * before creating contexts, not after.  No search may be in flight on the index; contexts stay valid. */
 idist_status idist_index_rehome(idist_index* idx);
 void idist_index_free(idist_index* idx);
 
