@@ -524,12 +524,6 @@ __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, 
 // Search::search (core/lib.rs:598-614) on one layer.  rows/row_stride: the
 // adjacency array (UpperNode: 32, ZeroNode: 64); links: `.take(links)`.
 // ---------------------------------------------------------------------------
-#ifndef IDIST_TP_PFA
-#define IDIST_TP_PFA 0
-#endif
-#ifndef IDIST_TP_OVL
-#define IDIST_TP_OVL 0
-#endif
 // first un-expanded entry after index `after`, -1 if none (does not move the cursor)
 __device__ __forceinline__ int w_peek_next(const WState& st, int after) {
     const int lane = lane_id();
@@ -635,8 +629,8 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     const int lane = lane_id();
     uint32_t guard = 0;
     const bool row_lane = lane < row_stride && lane < links;
-    constexpr bool PFA = LAT != kWalkClassic || IDIST_TP_PFA;   // adjacency requested one expansion ahead
-    constexpr bool OVL = LAT != kWalkClassic || IDIST_TP_OVL;   // visited bytes in flight during the first distance pass
+    constexpr bool PFA = LAT != kWalkClassic;   // adjacency requested one expansion ahead
+    constexpr bool OVL = LAT != kWalkClassic;   // visited bytes in flight during the first distance pass
     uint32_t pf_pid = kInvalid, pf_row = kInvalid;
     for (;;) {
         const int ci = w_pop(st);                         // :599-604
