@@ -234,7 +234,7 @@ def test_build_batched_matches_oracle_recall_gpu(engine_loader, oracle):
 
 
 @pytest.mark.gpu
-def test_c3_full_size_properties_gpu(engine_loader, oracle):
+def test_c3_full_size_properties_gpu(engine_loader, oracle, monkeypatch):
     """BASELINE config C3 at full size (1M x 300 f32): build on the GPU, then (i) size-independent
     properties, (ii) the oracle searching the SAME exported graph must agree bit for bit, (iii) exact
     recall against the MFMA-filtered brute force.  Runs with the placement calibration of the search context on."""
