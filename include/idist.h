@@ -27,9 +27,7 @@
  *   IDIST_LATENCY_NQ=<n>   batches of <= n queries (and build steps of <= n inserts) run the latency
  *                          variant of the graph walk; default 1024, 0 = never
  *   IDIST_WALK=classic     full batches / wide build steps with the classic walk instead of the overlap walk
- *   IDIST_VISITED_TRIES=<n> candidate allocations among which a context's visited array is chosen by timing
- *                          the search kernel (default 6, spaced 12 GB apart: IDIST_VISITED_SPACER_GB; 1 = take the first)
- *   IDIST_BLOOM=0          no LDS Bloom filter in front of the visited bytes
+ *   IDIST_BLOOM=0          no LDS Bloom filter in front of the visited bitmap
  *   IDIST_BRUTEFORCE=scan|mfma, IDIST_BF_SAMPLE=<n>   force a path of idist_bruteforce / its sample size
  *   IDIST_BUILD_PIPELINE=0 concurrent builds without the two-stream pipeline (a new point then sees all
  *                          points up to the previous step instead of the one before; graphs differ, quality
@@ -207,8 +205,12 @@ idist_status idist_index_rehome(idist_index* idx);
 void idist_index_free(idist_index* idx);
 
 /* ---- search ------------------------------------------------------------- */
-/* Search::default(), core/lib.rs:767-778: reusable scratch (visited set, W, candidates)
- * for up to `slots` queries in flight (0 = fill the chip). */
+/* Search::default(), core/lib.rs:767-778: reusable scratch (visited set, W, candidates) for up to `slots`
+ * queries in flight.  The visited set is one BIT per point and slot (core/types.rs:13-59 keeps a byte and a
+ * generation; membership is all that is observable).  slots = 0: like the reference's Search, which sizes its
+ * scratch on first use (core/lib.rs:363), the context starts with ONE slot (n/8 bytes) and grows to what the
+ * batches it is given need, at most a full chip (16 waves per CU = 4096 slots: 512 MB at 1M points).
+ * A context is bound to the index it was created for (by identity, not by address). */
 idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_search_ctx** out);
 void idist_search_ctx_free(idist_search_ctx* ctx);
 
@@ -237,6 +239,30 @@ idist_status idist_search_ctx_last_kernel_ms(idist_search_ctx* ctx, float* ms);
  * pairs; no synchronisation happens until this call).  *n_out = number written (<= cap). */
 #define IDIST_EVENT_RING 64u
 idist_status idist_search_ctx_kernel_times(idist_search_ctx* ctx, float* ms, uint32_t cap, uint32_t* n_out);
+
+/* ---- several GPUs of one node --------------------------------------------------- */
+/* `Hnsw` is Sync — Hnsw::search takes &self and every mutable bit lives in the caller's Search
+ * (core/lib.rs:352-356) — so the reference shares ONE index between all its threads.  Across GPUs the index
+ * is replicated once and the queries are block-partitioned; the build itself does not shard (every insert
+ * reads and mutates one graph): it runs on one GPU and is replicated ("replicas only").
+ *
+ * idist_replicate: replicas[i] receives a copy of `root` on devices[i], device to device over xGMI
+ * (hipMemcpyPeerAsync, peer access enabled where the link allows; all destinations are in flight together,
+ * one stream per destination).  devices[i] may be the root's own device (a plain copy).  Each replica is an
+ * ordinary index: search it with its own contexts, free it with idist_index_free.  On error nothing is left
+ * allocated.  (The multi-PROCESS flavour — one rank per GPU, RCCL broadcast into idist_index_alloc'ed
+ * replicas through idist_index_device_buffers — is instant-distance_amd/dist.py.) */
+idist_status idist_replicate(const idist_index* root, const int32_t* devices, uint32_t n_devices,
+                             idist_index** replicas);
+/* Hnsw::search for nq host queries over n_shards (replica, context) pairs: the queries are cut into the
+ * contiguous ranges [nq*i/n_shards, nq*(i+1)/n_shards) — what a caller partitioning over threads does —
+ * each searched by idist_search_batch on its own GPU from its own host thread, results written to the same
+ * ranges of the outputs.  No collective, no device-to-device traffic; the result is identical to one
+ * idist_search_batch over the whole batch. */
+idist_status idist_search_batch_sharded(const idist_index* const* replicas, idist_search_ctx* const* ctxs,
+                                        uint32_t n_shards, const float* queries, uint32_t nq,
+                                        uint32_t* out_pid, float* out_dist, uint32_t* out_count,
+                                        uint32_t* out_counters);
 
 /* Point::distance for id lists (core/lib.rs:780-782 as used at :709-710): out[q][i] =
  * distance(queries[q], points[ids[q][i]]) for i < n_ids; IDIST_INVALID ids give +inf.

@@ -110,6 +110,9 @@ SYMBOLS = {
     "idist_search_ctx_tie_overflowed": (C.c_int32, [_vp, C.POINTER(C.c_int32)]),
     "idist_search_ctx_last_kernel_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
     "idist_search_ctx_kernel_times": (C.c_int32, [_vp, _f32p, C.c_uint32, _u32p]),
+    "idist_replicate": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(_vp)]),
+    "idist_search_batch_sharded": (C.c_int32, [C.POINTER(_vp), C.POINTER(_vp), C.c_uint32, _f32p, C.c_uint32, _u32p, _f32p,
+                                               _u32p, _u32p]),
     "idist_distance_batch": (C.c_int32, [_vp, _f32p, C.c_uint32, _u32p, C.c_uint32, _f32p]),
     "idist_bruteforce": (C.c_int32, [_vp, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
 }

@@ -438,6 +438,36 @@ class Hnsw:
                                             C.c_void_p(d_count), C.c_void_p(d_counters) if d_counters else None,
                                             C.c_void_p(stream) if stream else None))
 
+    # -- several GPUs of one node (single process; the multi-process flavour is dist.py) --
+    def replicate(self, devices: Sequence[int]) -> list["Hnsw"]:
+        """One copy of this index per entry of `devices`, device to device over xGMI (idist_replicate).
+        The replicas share this index's host copy of the points (`Item.point` works on every replica)."""
+        devs = (C.c_int32 * max(len(devices), 1))(*[int(d) for d in devices])
+        outs = (C.c_void_p * max(len(devices), 1))()
+        _lib().check(_lib().idist_replicate(self._h, devs, len(devices), outs))
+        return [Hnsw(C.c_void_p(outs[i]), self.points, self._ef_search) for i in range(len(devices))]
+
+    @staticmethod
+    def search_batch_sharded(replicas: Sequence["Hnsw"], searches: Sequence[Search], queries, counters: bool = False) -> BatchResult:
+        """Hnsw::search for a batch block-partitioned over (replica, Search) pairs — one GPU each, one host
+        thread each, no collective (idist_search_batch_sharded).  Identical to `search_batch` on one replica."""
+        if not replicas or len(replicas) != len(searches):
+            raise ValueError("need one Search per replica")
+        q = _as_points(queries)
+        nq = q.shape[0]
+        ef = replicas[0]._ef_search
+        pid = np.full((nq, ef), INVALID, dtype=np.uint32)
+        dist = np.full((nq, ef), np.inf, dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        ctr = np.zeros((nq, 3), dtype=np.uint32) if counters else None
+        k = len(replicas)
+        hs = (C.c_void_p * k)(*[r._h for r in replicas])
+        cs = (C.c_void_p * k)(*[s._bind(r) for r, s in zip(replicas, searches)])
+        L = _lib()
+        L.check(L.idist_search_batch_sharded(hs, cs, k, _capi.f32p(q), nq, _capi.u32p(pid), _capi.f32p(dist), _capi.u32p(cnt),
+                                             _capi.u32p(ctr) if counters else None))
+        return BatchResult(pid, dist, cnt, ctr)
+
     def search(self, point, search: Search) -> Search:
         """Search the index for the points nearest to `point` (core/lib.rs:352-383).
 

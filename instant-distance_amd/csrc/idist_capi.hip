@@ -14,11 +14,13 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace idist;
@@ -124,6 +126,7 @@ idist_status validate_config(const idist_config* cfg, bool for_build) {
 }  // namespace
 
 struct idist_index {
+    uint64_t uid = 0;            // never reused: a context is bound to (pointer, uid), not to the pointer alone
     int32_t device = 0;
     idist_config cfg{};
     uint32_t n = 0, dim = 0;
@@ -162,16 +165,34 @@ struct idist_progress {
     unsigned long long total = 0;
 };
 
+// Knobs read from the environment (measurement / test only), sampled once per context or build — not per launch.
+struct Knobs {
+    uint32_t latency_nq = 1024;   // IDIST_LATENCY_NQ: batches up to this many queries run the latency walk (0 = never)
+    bool classic = false;         // IDIST_WALK=classic
+    bool bloom = true;            // IDIST_BLOOM=0 disables the LDS Bloom filter in front of the visited bitmap
+    int tune = -1;                // IDIST_TUNE=<i> (tuning builds only, -DIDIST_TUNE): i-th experimental walk variant
+    static Knobs from_env() {
+        Knobs k;
+        if (const char* e = getenv("IDIST_TUNE")) k.tune = atoi(e);
+        if (const char* e = getenv("IDIST_LATENCY_NQ")) k.latency_nq = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char* e = getenv("IDIST_WALK")) k.classic = e[0] == 'c';
+        if (const char* e = getenv("IDIST_BLOOM")) k.bloom = e[0] != '0';
+        return k;
+    }
+};
+
 struct idist_search_ctx {
     const idist_index* idx = nullptr;
-    uint32_t slots = 0;
-    size_t vis_stride = 0;
-    uint8_t* d_visited = nullptr;
-    uint8_t* d_gen = nullptr;
+    uint64_t idx_uid = 0;          // uid of the index this context was made for
+    uint32_t slots_req = 0;        // what the caller asked for (0 = as many as the batches need, up to a full chip)
+    uint32_t slots = 0;            // query slots currently backed by a visited bitmap
+    VisGeom vis{};
+    uint32_t* d_visited = nullptr; // [slots][vis.slot_words], all-zero between launches
     uint32_t* d_next = nullptr;    // [0] queue head, [1] status
     hipStream_t stream = nullptr;
     hipEvent_t ev0[IDIST_EVENT_RING] = {nullptr}, ev1[IDIST_EVENT_RING] = {nullptr};
     uint64_t n_launch = 0;
+    Knobs knobs;
     // staging for the host-pointer API
     float* d_q = nullptr;
     uint32_t* d_pid = nullptr;
@@ -181,6 +202,9 @@ struct idist_search_ctx {
     size_t cap_q = 0, cap_out = 0, cap_nq = 0;
     bool tie_overflowed = false;
     uint32_t tie_cap = 0;          // tie capacity this context escalated to (0 = the index's)
+    // copies of what idist_search_ctx_status needs, so that it never reads through `idx`
+    int32_t tie_policy = IDIST_TIES_STRICT;
+    uint32_t base_tie_cap = kTieCap, stride = 0, last_ef = 0;
 };
 
 namespace {
@@ -201,7 +225,9 @@ idist_status index_alloc(uint32_t n, uint32_t dim, const idist_config* cfg, cons
     if (n == 0xFFFFFFFFu) return fail(IDIST_ERR_INVALID_ARG, "n must be < u32::MAX (core/lib.rs:256)");
     if (n_upper >= IDIST_MAX_LAYERS) return fail(IDIST_ERR_INVALID_ARG, "more than %u layers", IDIST_MAX_LAYERS);
     CHK(check_device(device));
+    static std::atomic<uint64_t> next_uid{1};
     idist_index* ix = new idist_index();
+    ix->uid = next_uid.fetch_add(1);
     ix->device = device;
     ix->cfg = *cfg;
     ix->n = n;
@@ -262,35 +288,15 @@ idist_status load_points_host(idist_index* ix, const float* h_nat) {
 }
 
 uint32_t default_slots(const idist_index* ix) {
-    // fill the chip (16 single-wave workgroups per CU) within a visited-set memory budget: one byte per point
-    // and slot (core/types.rs:13-59), so beyond ~16M points the slots — not the CUs — bound the concurrency
-    // (100M points: 64 GB buy 640 slots)
+    // fill the chip (16 single-wave workgroups per CU) within a memory budget for the visited bitmaps: one bit per
+    // point and slot (core/types.rs:13-59), i.e. 512 MB for 4096 slots at 1M points, 5 GB at 10M
     size_t freeb = 0, totalb = 0;
     if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) freeb = (size_t)8 << 30;
     const size_t budget = std::min<size_t>(freeb / 3, (size_t)64 << 30);
-    const size_t vis = (((size_t)ix->n + 255) & ~(size_t)255);
+    const size_t vis = (size_t)vis_geometry(ix->n).slot_words * 4;
     size_t s = (size_t)ix->n_cu * 16;
     if (vis) s = std::min(s, std::max<size_t>(budget / vis, 64));
     return (uint32_t)std::max<size_t>(s, 1);
-}
-
-// Batches up to this many queries run the latency variant of the search kernel (IDIST_LATENCY_NQ overrides;
-// 0 = never).  Above it the chip is full and the leaner throughput variant wins.
-uint32_t latency_nq() {
-    if (const char* e = getenv("IDIST_LATENCY_NQ")) return (uint32_t)strtoul(e, nullptr, 10);
-    return 1024u;
-}
-
-// A/B knob for measurements: IDIST_WALK=classic runs full batches / wide build steps with the classic walk
-bool classic_walk() {
-    const char* e = getenv("IDIST_WALK");
-    return e && e[0] == 'c';
-}
-
-// A/B knob for measurements: IDIST_BLOOM=0 disables the LDS Bloom filter in front of the visited bytes
-bool use_bloom_filter() {
-    const char* e = getenv("IDIST_BLOOM");
-    return !(e && e[0] == '0');
 }
 
 thread_local uint32_t g_tie_cap_msg = kTieCap;
@@ -316,14 +322,15 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     const uint32_t cap = std::min<uint32_t>(cfg.max_batch == 0 ? 8192u : cfg.max_batch, std::max<uint32_t>(1u, n / 32u));
     const uint32_t slots_max = default_slots(ix);
     const uint32_t slots = std::min(cap, slots_max);
-    const size_t vis_stride = ((size_t)n + 255) & ~(size_t)255;
+    const VisGeom vg = vis_geometry(n);
+    const Knobs knobs = Knobs::from_env();
     const uint32_t tie_cap = tie_capacity(cfg);
     const uint32_t wcap = cfg.ef_construction + 64 + tie_cap + 64;
-    const size_t smem = smem_bytes(ix->L.stride, wcap, true);
+    const size_t smem = smem_bytes(ix->L.stride, wcap, true, kBloomWords, vg.dirty_words);
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave (> 64 KiB)", smem);
     // steps too narrow to fill the chip (the early graph, max_batch = 1) run the latency variant of the descent
-    const size_t smem_lat = smem_bytes(ix->L.stride, wcap, true, kBloomLatWords);
-    const uint32_t lat_nq = smem_lat <= 64 * 1024 ? latency_nq() : 0u;
+    const size_t smem_lat = smem_bytes(ix->L.stride, wcap, true, kBloomLatWords, vg.dirty_words);
+    const uint32_t lat_nq = smem_lat <= 64 * 1024 ? knobs.latency_nq : 0u;
 
     // step B tile: as many selected rows on chip as fit 64 KiB of LDS next to 8 staging slots
     uint32_t rt = 8;
@@ -339,7 +346,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     const size_t smemA2 = smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction);
     if (smemA2 > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim %u / ef_construction %u need %zu B of LDS per wave in the build (> 64 KiB)", ix->dim, cfg.ef_construction, smemA2);
 
-    uint8_t *d_vis = nullptr, *d_gen = nullptr;
+    uint32_t* d_vis = nullptr;
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
     uint32_t* d_small = nullptr;           // [0] n_touched, [1..5] queue (A, B, n_slow, B2, A2), [6] status
@@ -369,7 +376,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         if (s2) hipStreamDestroy(s2);
         for (int i = 0; i < 2; i++) { if (evA[i]) hipEventDestroy(evA[i]); if (evS[i]) hipEventDestroy(evS[i]); }
         hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount); hipFree(d_dlog);
-        hipFree(d_vis); hipFree(d_gen); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
+        hipFree(d_vis); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
         if (e0) hipEventDestroy(e0);
         if (e1) hipEventDestroy(e1);
@@ -382,10 +389,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
             return fail(IDIST_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
         }                                                                                           \
     } while (0)
-    BCHK(hipMalloc((void**)&d_vis, (size_t)slots * vis_stride));
-    BCHK(hipMemset(d_vis, 0, (size_t)slots * vis_stride));
-    BCHK(hipMalloc((void**)&d_gen, std::max<size_t>(slots, 256)));
-    BCHK(hipMemset(d_gen, 0, std::max<size_t>(slots, 256)));
+    BCHK(hipMalloc((void**)&d_vis, (size_t)slots * vg.slot_words * 4));
+    BCHK(hipMemset(d_vis, 0, (size_t)slots * vg.slot_words * 4));
     BCHK(hipMalloc((void**)&d_nbr_dist, (size_t)n * IDIST_M2 * 4));
     BCHK(hipMemset(d_nbr_dist, 0, (size_t)n * IDIST_M2 * 4));
     BCHK(hipMalloc((void**)&d_nbr_aux, (size_t)n * IDIST_M2 * 4));
@@ -424,10 +429,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     a.wcap = wcap;
     a.keep_pruned = cfg.keep_pruned ? 1u : 0u;
     a.has_heuristic = cfg.has_heuristic ? 1u : 0u;
-    a.use_bloom = use_bloom_filter() ? 1u : 0u;
+    a.use_bloom = knobs.bloom ? 1u : 0u;
     a.visited = d_vis;
-    a.vis_stride = vis_stride;
-    a.gen = d_gen;
+    a.vis = vg;
     a.edge_pid = d_edge_pid;
     a.edge_dist = d_edge_dist;
     a.head = d_head;
@@ -449,7 +453,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     a.tie_cap = tie_cap;
     if (const char* e = getenv("IDIST_BUILD_CHUNK")) a.chunk = (uint32_t)atoi(e);
     const size_t smemF = smem_bytes_update_fast(ix->L.stride);
-    const bool classic = classic_walk();
+    const bool classic = knobs.classic;
     const bool no_fast = getenv("IDIST_BUILD_NO_FAST") != nullptr;   // test knob: route every update through B2
     a.stats = d_stats;
 
@@ -625,9 +629,40 @@ idist_status build_common(const void* points, bool on_device, uint32_t n, uint32
     }
 }
 
+// A context belongs to ONE index: `ctx->idx == idx` alone would accept a new index that happens to live at the
+// address of a freed one (its bitmaps are sized for the old n).
+idist_status check_ctx(const idist_index* idx, const idist_search_ctx* ctx) {
+    if (!idx || !ctx || ctx->idx != idx || ctx->idx_uid != idx->uid)
+        return fail(IDIST_ERR_INVALID_ARG, "ctx does not belong to idx");
+    return IDIST_OK;
+}
+
+// Back `want` query slots with visited bitmaps (Search::default() grows its scratch on first use too,
+// core/lib.rs:363).  Existing slots are all-zero between launches, so growing is allocate + clear.
+idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stream) {
+    if (want <= ctx->slots) return IDIST_OK;
+    uint32_t s = 1;
+    while (s < want) s <<= 1;                                    // few distinct sizes: 1, 2, 4, ... up to the cap
+    const uint32_t cap = ctx->slots_req ? ctx->slots_req : default_slots(ctx->idx);
+    s = std::max(std::min(s, cap), 1u);
+    if (s <= ctx->slots) return IDIST_OK;
+    const size_t bytes = std::max<size_t>((size_t)s * ctx->vis.slot_words * 4, 256);
+    uint32_t* fresh = nullptr;
+    HIPCHK(hipDeviceSynchronize());                              // nothing may still be walking on the old bitmaps
+    HIPCHK(hipMalloc((void**)&fresh, bytes));
+    hipError_t e = hipMemsetAsync(fresh, 0, bytes, stream);
+    if (e != hipSuccess) { hipFree(fresh); return fail(IDIST_ERR_HIP, "visited bitmaps: %s", hipGetErrorString(e)); }
+    hipFree(ctx->d_visited);
+    ctx->d_visited = fresh;
+    ctx->slots = s;
+    return IDIST_OK;
+}
+
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
                            uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream) {
     const uint32_t ef = ix->cfg.ef_search;
+    CHK(ensure_slots(ctx, nq, stream));
+    ctx->last_ef = ef;
     SearchArgs a{};
     a.queries = d_q;
     a.nq = nq;
@@ -639,16 +674,17 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     a.out_count = d_cnt;
     a.out_counters = d_ctr;
     a.visited = ctx->d_visited;
-    a.vis_stride = ctx->vis_stride;
-    a.gen = ctx->d_gen;
+    a.vis = ctx->vis;
     a.next = ctx->d_next;
     a.status = ctx->d_next + 1;
-    a.use_bloom = use_bloom_filter() ? 1u : 0u;
+    a.use_bloom = ctx->knobs.bloom ? 1u : 0u;
     // narrow batches cannot fill the chip: run the latency variant (same results, overlapped round trips)
-    const bool lat = nq <= latency_nq() && smem_bytes(ix->L.stride, a.wcap, false, kBloomLatWords) <= 64 * 1024;
-    const size_t smem = smem_bytes(ix->L.stride, a.wcap, false, lat ? kBloomLatWords : kBloomWords);
+    const bool lat = nq <= ctx->knobs.latency_nq &&
+                     smem_bytes(ix->L.stride, a.wcap, false, kBloomLatWords, a.vis.dirty_words) <= 64 * 1024;
+    const size_t smem = smem_bytes(ix->L.stride, a.wcap, false, lat ? kBloomLatWords : kBloomWords, a.vis.dirty_words);
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_search need %zu B of LDS per wave (> 64 KiB)", smem);
     const uint32_t grid = std::min(nq, ctx->slots);
+    const bool classic = ctx->knobs.classic;
     IndexView view = ix->view();
     HIPCHK(hipMemsetAsync(ctx->d_next, 0, 4, stream));
     const uint32_t slot = (uint32_t)(ctx->n_launch % IDIST_EVENT_RING);
@@ -658,7 +694,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
         if (lat) {                                                           \
             auto kS = search_kernel<NB_, RS_, TAIL_, kWalkLatency>;          \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);               \
-        } else if (classic_walk()) {                                         \
+        } else if (classic) {                                                \
             auto kS = search_kernel<NB_, RS_, TAIL_, kWalkClassic>;          \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);               \
         } else {                                                             \
@@ -666,82 +702,39 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);               \
         }                                                                    \
     }
+#ifdef IDIST_TUNE
+    // tuning build: full 300-d batches through one of the experimental variants of the overlap walk
+    if (!lat && ctx->knobs.tune >= 0 && ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) {
+#define TUNE_CASE(I_, CODE_)                                              \
+    case I_: {                                                            \
+        auto kS = search_kernel<9, 1, 1, CODE_>;                          \
+        IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                \
+        break;                                                            \
+    }
+        switch (ctx->knobs.tune) {
+            TUNE_CASE(0, walk_code(kWalkOverlap, 2, false, 0))    // = production
+            TUNE_CASE(1, walk_code(kWalkOverlap, 2, true, 0))
+            TUNE_CASE(2, walk_code(kWalkOverlap, 2, true, 3))
+            TUNE_CASE(3, walk_code(kWalkOverlap, 3, false, 0))
+            TUNE_CASE(4, walk_code(kWalkOverlap, 3, true, 2))
+            TUNE_CASE(5, walk_code(kWalkOverlap, 4, true, 2))
+            TUNE_CASE(6, walk_code(kWalkOverlap, 1, true, 4))
+            TUNE_CASE(7, walk_code(kWalkOverlap, 1, false, 4))
+            TUNE_CASE(8, walk_code(kWalkOverlap, 4, false, 2))
+            TUNE_CASE(9, walk_code(kWalkOverlap, 2, false, 3))
+            TUNE_CASE(10, walk_code(kWalkOverlap, 8, true, 1))
+            TUNE_CASE(11, walk_code(kWalkOverlap, 6, true, 1))
+            TUNE_CASE(12, walk_code(kWalkOverlap, 8, false, 1))
+            default: return fail(IDIST_ERR_INVALID_ARG, "IDIST_TUNE=%d: no such variant", ctx->knobs.tune);
+        }
+#undef TUNE_CASE
+    } else
+#endif
     IDIST_DISPATCH(ix->L, LAUNCH_SEARCH);
 #undef LAUNCH_SEARCH
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
     ctx->n_launch++;
-    return IDIST_OK;
-}
-
-// Where a context's visited array (one byte per point and slot: 4 GB at 1M points) lands in HBM decides ~11 % of the
-// search kernel's time: of ten identical allocations in one process, the same four made every launch slower, on any
-// stream (profiles/probe_r01_visited_placement.jsonl) — an interplay with the index's own placement that a write
-// probe on the array alone does not show.  So the array is chosen among up to IDIST_VISITED_TRIES (default 6)
-// candidate allocations by timing the real search kernel on each (2048 stored rows as queries, results discarded);
-// all candidates stay allocated until the choice is made (a freed block would simply be handed out again).
-idist_status place_visited(const idist_index* idx, idist_search_ctx* c, size_t vb) {
-    int tries = 6;
-    if (const char* e = getenv("IDIST_VISITED_TRIES")) tries = std::min(8, std::max(1, atoi(e)));
-    size_t freeb = 0, totalb = 0;
-    const uint32_t ef = idx->cfg.ef_search;
-    if (hipMemGetInfo(&freeb, &totalb) != hipSuccess || idx->n < 65536 || c->slots < 1024 || ef == 0 || ef > 512) return IDIST_OK;
-    tries = (int)std::min<size_t>((size_t)tries, freeb / 3 / vb);
-    if (tries < 2) return IDIST_OK;
-    const uint32_t nq = 2048;
-    uint8_t* cand[8] = {c->d_visited};
-    int have = 1;
-    float* d_q = nullptr;
-    float* d_dist = nullptr;
-    uint32_t *d_pid = nullptr, *d_cnt = nullptr;
-    auto release = [&]() { hipFree(d_q); hipFree(d_dist); hipFree(d_pid); hipFree(d_cnt); };
-    if (hipMalloc((void**)&d_q, (size_t)nq * idx->dim * 4) != hipSuccess || hipMalloc((void**)&d_pid, (size_t)nq * ef * 4) != hipSuccess ||
-        hipMalloc((void**)&d_dist, (size_t)nq * ef * 4) != hipSuccess || hipMalloc((void**)&d_cnt, (size_t)nq * 4) != hipSuccess ||
-        hipMemcpy2D(d_q, (size_t)idx->dim * 4, idx->d_points, (size_t)idx->L.stride * 4, (size_t)idx->dim * 4, nq, hipMemcpyDeviceToDevice) != hipSuccess) {
-        release();
-        (void)hipGetLastError();
-        return IDIST_OK;                                   // no calibration, keep the first allocation
-    }
-    // Consecutive allocations tend to share their class (the classes come in runs of several 4-GB blocks), so the
-    // candidates are spread out: a spacer of `IDIST_VISITED_SPACER_GB` (default 12) is held between two of them
-    // while they are allocated, memory permitting.
-    size_t spacer = (size_t)12 << 30;
-    if (const char* e = getenv("IDIST_VISITED_SPACER_GB")) spacer = (size_t)atoll(e) << 30;
-    void* spacers[8] = {nullptr};
-    for (; have < tries; have++) {
-        if (spacer && hipMemGetInfo(&freeb, &totalb) == hipSuccess && freeb > 2 * (spacer + vb) + ((size_t)16 << 30)) {
-            if (hipMalloc(&spacers[have], spacer) != hipSuccess) { spacers[have] = nullptr; (void)hipGetLastError(); }
-        }
-        if (hipMalloc((void**)&cand[have], vb) != hipSuccess || hipMemset(cand[have], 0, vb) != hipSuccess) {
-            hipFree(cand[have]);
-            (void)hipGetLastError();
-            break;
-        }
-    }
-    for (int t = 0; t < 8; t++) hipFree(spacers[t]);
-    int pick = 0;
-    float best = 1e30f;
-    for (int t = 0; t < have; t++) {
-        c->d_visited = cand[t];
-        float ms = 1e30f;
-        for (int rep = 0; rep < 3; rep++) {
-            float m = 0.f;
-            if (launch_search(idx, c, d_q, nq, d_pid, d_dist, d_cnt, nullptr, c->stream) != IDIST_OK ||
-                idist_search_ctx_last_kernel_ms(c, &m) != IDIST_OK) { m = 1e30f; break; }
-            if (rep > 0 && m < ms) ms = m;
-        }
-        if (getenv("IDIST_DEBUG_PTRS")) fprintf(stderr, "[idist] visited candidate %d: %p calibration %.3f ms\n", t, (void*)cand[t], ms);
-        if (ms < best) { best = ms; pick = t; }
-    }
-    hipError_t e = hipStreamSynchronize(c->stream);
-    for (int t = 0; t < have; t++)
-        if (t != pick) hipFree(cand[t]);
-    c->d_visited = cand[pick];
-    c->n_launch = 0;                                       // the calibration launches are not the caller's
-    const uint32_t zero2[2] = {0, 0};                      // queue head and device status of the throw-away searches
-    if (e == hipSuccess) e = hipMemcpy(c->d_next, zero2, 8, hipMemcpyHostToDevice);
-    release();
-    if (e != hipSuccess) return fail(IDIST_ERR_HIP, "visited placement: %s", hipGetErrorString(e));
     return IDIST_OK;
 }
 
@@ -1011,18 +1004,18 @@ idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_
     HIPCHK(hipSetDevice(idx->device));
     idist_search_ctx* c = new idist_search_ctx();
     c->idx = idx;
-    c->slots = slots ? slots : default_slots(idx);
-    c->vis_stride = ((size_t)idx->n + 255) & ~(size_t)255;
+    c->idx_uid = idx->uid;
+    c->slots_req = slots;
+    c->vis = vis_geometry(idx->n);
+    c->knobs = Knobs::from_env();
+    c->tie_policy = idx->cfg.tie_policy;
+    c->base_tie_cap = tie_capacity(idx->cfg);
+    c->stride = idx->L.stride;
     auto bail = [&](hipError_t e) {
         idist_search_ctx_free(c);
         return fail(IDIST_ERR_HIP, "search ctx allocation failed: %s", hipGetErrorString(e));
     };
     hipError_t e;
-    const size_t vb = std::max<size_t>((size_t)c->slots * c->vis_stride, 256);
-    if ((e = hipMalloc((void**)&c->d_visited, vb)) != hipSuccess) return bail(e);
-    if ((e = hipMemset(c->d_visited, 0, vb)) != hipSuccess) return bail(e);
-    if ((e = hipMalloc((void**)&c->d_gen, std::max<size_t>(c->slots, 256))) != hipSuccess) return bail(e);
-    if ((e = hipMemset(c->d_gen, 0, std::max<size_t>(c->slots, 256))) != hipSuccess) return bail(e);
     if ((e = hipMalloc((void**)&c->d_next, 256)) != hipSuccess) return bail(e);
     if ((e = hipMemset(c->d_next, 0, 256)) != hipSuccess) return bail(e);
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail(e);
@@ -1030,7 +1023,9 @@ idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_
         if ((e = hipEventCreate(&c->ev0[i])) != hipSuccess) return bail(e);
         if ((e = hipEventCreate(&c->ev1[i])) != hipSuccess) return bail(e);
     }
-    if (place_visited(idx, c, vb) != IDIST_OK) { idist_search_ctx_free(c); return IDIST_ERR_HIP; }
+    // Search::default() is cheap (core/lib.rs:767-778): one slot = n/8 bytes now; the bitmaps of further slots
+    // are allocated when a batch first needs them (ensure_slots), or right away if the caller named a count
+    if (ensure_slots(c, slots ? slots : 1u, nullptr) != IDIST_OK) { idist_search_ctx_free(c); return IDIST_ERR_HIP; }
     // the scratch above was cleared on the null stream; a caller's non-blocking stream would not wait for it
     if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return bail(e);
     *out = c;
@@ -1039,9 +1034,8 @@ idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_
 
 void idist_search_ctx_free(idist_search_ctx* c) {
     if (!c) return;
-    if (c->idx) hipSetDevice(c->idx->device);
+    // (the index may already be gone: nothing of it is touched here)
     hipFree(c->d_visited);
-    hipFree(c->d_gen);
     hipFree(c->d_next);
     hipFree(c->d_q);
     hipFree(c->d_pid);
@@ -1059,7 +1053,7 @@ void idist_search_ctx_free(idist_search_ctx* c) {
 idist_status idist_search_batch_device(const idist_index* idx, idist_search_ctx* ctx, const void* d_queries,
                                        uint32_t nq, void* d_out_pid, void* d_out_dist, void* d_out_count,
                                        void* d_out_counters, void* hip_stream) {
-    if (!idx || !ctx || ctx->idx != idx) return fail(IDIST_ERR_INVALID_ARG, "ctx does not belong to idx");
+    CHK(check_ctx(idx, ctx));
     if (nq == 0) return IDIST_OK;
     if (!d_queries || !d_out_count) return fail(IDIST_ERR_INVALID_ARG, "null device pointer");
     HIPCHK(hipSetDevice(idx->device));
@@ -1081,12 +1075,13 @@ idist_status idist_search_ctx_status(idist_search_ctx* ctx) {
     if (st & kStTieOverflow) {
         ctx->tie_overflowed = true;
         // strict: later launches of this context get a larger tie region (x4, at most 4096 entries, LDS permitting)
-        const uint32_t cap = std::max(tie_capacity(ctx->idx->cfg), ctx->tie_cap), next = std::min<uint32_t>(4096u, cap * 4u);
-        if (ctx->idx->cfg.tie_policy == IDIST_TIES_STRICT && next > cap &&
-            smem_bytes(ctx->idx->L.stride, ctx->idx->cfg.ef_search + 64 + next + 8, false) <= 64 * 1024)
+        const uint32_t cap = std::max(ctx->base_tie_cap, ctx->tie_cap), next = std::min<uint32_t>(4096u, cap * 4u);
+        if (ctx->tie_policy == IDIST_TIES_STRICT && next > cap &&
+            smem_bytes(ctx->stride, ctx->last_ef + 64 + next + 8, false, kBloomWords, ctx->vis.dirty_words) <= 64 * 1024)
             ctx->tie_cap = next;
+        g_tie_cap_msg = cap;
     }
-    return device_status_to_code(st, ctx->idx->cfg.tie_policy);
+    return device_status_to_code(st, ctx->tie_policy);
 }
 
 idist_status idist_search_ctx_tie_overflowed(idist_search_ctx* ctx, int32_t* out) {
@@ -1121,7 +1116,7 @@ idist_status idist_search_ctx_kernel_times(idist_search_ctx* ctx, float* ms, uin
 
 idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, const float* queries, uint32_t nq,
                                 uint32_t* out_pid, float* out_dist, uint32_t* out_count, uint32_t* out_counters) {
-    if (!idx || !ctx || ctx->idx != idx) return fail(IDIST_ERR_INVALID_ARG, "ctx does not belong to idx");
+    CHK(check_ctx(idx, ctx));
     if (nq == 0) return IDIST_OK;
     if (!queries || !out_count) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
     const uint32_t ef = idx->cfg.ef_search;
@@ -1163,6 +1158,154 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
         return s;
     }
 }
+
+// ---- several GPUs of one node: replicate once, shard the queries ----
+idist_status idist_replicate(const idist_index* root, const int32_t* devices, uint32_t n_devices, idist_index** replicas) {
+    if (!root || !replicas || (n_devices && !devices)) return fail(IDIST_ERR_INVALID_ARG, "null argument");
+    for (uint32_t i = 0; i < n_devices; i++) replicas[i] = nullptr;
+    auto undo = [&](idist_status s) {
+        const std::string keep = g_err;
+        for (uint32_t i = 0; i < n_devices; i++) { idist_index_free(replicas[i]); replicas[i] = nullptr; }
+        hipSetDevice(root->device);
+        g_err = keep;
+        return s;
+    };
+    std::vector<hipStream_t> streams(n_devices, nullptr);
+    auto drop_streams = [&]() {
+        for (uint32_t i = 0; i < n_devices; i++)
+            if (streams[i]) { hipSetDevice(devices[i]); hipStreamDestroy(streams[i]); }
+    };
+    const size_t pb = (size_t)root->n * root->L.stride * 4, zb = (size_t)root->n * IDIST_M2 * 4, ub = root->upper_rows * IDIST_M * 4;
+    // make sure nothing is still writing the root's buffers (a build on another stream)
+    if (hipSetDevice(root->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        return fail(IDIST_ERR_HIP, "replicate: root device %d: %s", root->device, hipGetErrorString(hipGetLastError()));
+    for (uint32_t i = 0; i < n_devices; i++) {
+        idist_index* r = nullptr;
+        idist_status st = index_alloc(root->n, root->dim, &root->cfg, root->layer_len, root->n_upper, devices[i], &r);   // sets the device
+        if (st != IDIST_OK) { drop_streams(); return undo(st); }
+        replicas[i] = r;
+        r->stats = root->stats;
+        hipError_t e = hipSuccess;
+        if (devices[i] != root->device) {
+            int can = 0;
+            e = hipDeviceCanAccessPeer(&can, devices[i], root->device);
+            if (e == hipSuccess && can) {
+                e = hipDeviceEnablePeerAccess(root->device, 0);       // direct xGMI reads; already-enabled is fine
+                if (e != hipSuccess) { (void)hipGetLastError(); e = hipSuccess; }
+            }
+        }
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking);
+        // all destinations' copies are queued before any is waited for: the root streams to its peers in parallel
+        // (xGMI is point to point: one link per destination)
+        if (e == hipSuccess && pb) e = hipMemcpyPeerAsync(r->d_points, devices[i], root->d_points, root->device, pb, streams[i]);
+        if (e == hipSuccess && zb) e = hipMemcpyPeerAsync(r->d_zero, devices[i], root->d_zero, root->device, zb, streams[i]);
+        if (e == hipSuccess && ub) e = hipMemcpyPeerAsync(r->d_upper, devices[i], root->d_upper, root->device, ub, streams[i]);
+        if (e != hipSuccess) {
+            fail(IDIST_ERR_HIP, "replicate to device %d: %s", devices[i], hipGetErrorString(e));
+            drop_streams();
+            return undo(IDIST_ERR_HIP);
+        }
+    }
+    for (uint32_t i = 0; i < n_devices; i++) {
+        hipSetDevice(devices[i]);
+        hipError_t e = hipStreamSynchronize(streams[i]);
+        if (e != hipSuccess) {
+            fail(IDIST_ERR_HIP, "replicate to device %d: %s", devices[i], hipGetErrorString(e));
+            drop_streams();
+            return undo(IDIST_ERR_HIP);
+        }
+    }
+    drop_streams();
+    hipSetDevice(root->device);
+    return IDIST_OK;
+}
+
+idist_status idist_search_batch_sharded(const idist_index* const* replicas, idist_search_ctx* const* ctxs, uint32_t n_shards,
+                                        const float* queries, uint32_t nq, uint32_t* out_pid, float* out_dist,
+                                        uint32_t* out_count, uint32_t* out_counters) {
+    if (!replicas || !ctxs || n_shards == 0) return fail(IDIST_ERR_INVALID_ARG, "no shards");
+    for (uint32_t i = 0; i < n_shards; i++) {
+        CHK(check_ctx(replicas[i], ctxs[i]));
+        if (replicas[i]->n != replicas[0]->n || replicas[i]->dim != replicas[0]->dim ||
+            replicas[i]->cfg.ef_search != replicas[0]->cfg.ef_search)
+            return fail(IDIST_ERR_INVALID_ARG, "shard %u is not a replica of shard 0 (n, dim or ef_search differ)", i);
+        for (uint32_t j = 0; j < i; j++)
+            if (ctxs[j] == ctxs[i]) return fail(IDIST_ERR_INVALID_ARG, "shards %u and %u share a search context", j, i);
+    }
+    if (nq == 0) return IDIST_OK;
+    if (!queries || !out_count) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
+    const uint32_t ef = replicas[0]->cfg.ef_search, dim = replicas[0]->dim;
+    std::vector<idist_status> st(n_shards, IDIST_OK);
+    std::vector<std::string> msg(n_shards);
+    auto work = [&](uint32_t i) {
+        // contiguous block partition, the reference's own concurrency model (callers split queries over threads)
+        const uint32_t lo = (uint32_t)((uint64_t)nq * i / n_shards), hi = (uint32_t)((uint64_t)nq * (i + 1) / n_shards);
+        if (hi == lo) return;
+        st[i] = idist_search_batch(replicas[i], ctxs[i], queries + (size_t)lo * dim, hi - lo,
+                                   out_pid ? out_pid + (size_t)lo * ef : nullptr, out_dist ? out_dist + (size_t)lo * ef : nullptr,
+                                   out_count + lo, out_counters ? out_counters + (size_t)lo * 3 : nullptr);
+        if (st[i] != IDIST_OK) msg[i] = g_err;                 // g_err is thread-local
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t i = 1; i < n_shards; i++) threads.emplace_back(work, i);
+    work(0);
+    for (auto& t : threads) t.join();
+    for (uint32_t i = 0; i < n_shards; i++)
+        if (st[i] != IDIST_OK) return fail(st[i], "shard %u (device %d): %s", i, replicas[i]->device, msg[i].c_str());
+    return IDIST_OK;
+}
+
+#ifdef IDIST_TUNE
+// tuning build only (libidist_tune.so; not part of the ABI): place a context's visited bitmaps / an index's point rows
+// at a caller-chosen device address (placement studies).  The previous buffer is NOT freed; the caller owns `ptr`.
+extern "C" idist_status idist_tune_set_visited(idist_search_ctx* ctx, void* ptr, uint32_t slots) {
+    if (hipDeviceSynchronize() != hipSuccess) return IDIST_ERR_HIP;
+    if (hipMemset(ptr, 0, (size_t)slots * ctx->vis.slot_words * 4) != hipSuccess) return IDIST_ERR_HIP;
+    ctx->d_visited = (uint32_t*)ptr;
+    ctx->slots = slots;
+    ctx->slots_req = slots;
+    return IDIST_OK;
+}
+// which: 0 = point rows, 1 = zero layer, 2 = upper layers.  `src` = where a pristine copy lives (never overlapping ptr).
+extern "C" idist_status idist_tune_move_buffer(idist_index* idx, int which, void* ptr, const void* src) {
+    if (hipDeviceSynchronize() != hipSuccess) return IDIST_ERR_HIP;
+    const size_t bytes = which == 0 ? (size_t)idx->n * idx->L.stride * 4 : which == 1 ? (size_t)idx->n * IDIST_M2 * 4 : idx->upper_rows * IDIST_M * 4;
+    if (hipMemcpy(ptr, src, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return IDIST_ERR_HIP;
+    if (which == 0) idx->d_points = (float*)ptr; else if (which == 1) idx->d_zero = (uint32_t*)ptr; else idx->d_upper = (uint32_t*)ptr;
+    return hipDeviceSynchronize() == hipSuccess ? IDIST_OK : IDIST_ERR_HIP;
+}
+// kernel time (ms, HIP events, best of reps) of the stand-alone gather-L2 kernel over n_ids pseudo-random rows per query
+extern "C" idist_status idist_tune_gather_ms(const idist_index* idx, uint32_t nq, uint32_t n_ids, int reps, float* ms_out) {
+    float* d_q = nullptr; float* d_out = nullptr; uint32_t* d_ids = nullptr;
+    std::vector<uint32_t> ids((size_t)nq * n_ids);
+    uint64_t x = 88172645463325252ull;
+    for (auto& v : ids) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (uint32_t)(x % idx->n); }
+    if (hipMalloc((void**)&d_q, (size_t)nq * idx->dim * 4) != hipSuccess || hipMalloc((void**)&d_out, ids.size() * 4) != hipSuccess ||
+        hipMalloc((void**)&d_ids, ids.size() * 4) != hipSuccess) return IDIST_ERR_HIP;
+    hipMemset(d_q, 0, (size_t)nq * idx->dim * 4);
+    hipMemcpy(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice);
+    const uint32_t chunks = (n_ids + 63u) / 64u;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)nq * chunks, 256u * 16u);
+    const size_t smem = smem_bytes(idx->L.stride, 0, false);
+    IndexView view = idx->view();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int r = 0; r < reps; r++) {
+        hipEventRecord(e0, nullptr);
+        auto kD = distance_batch_kernel<9, 1, 1>;
+        IDIST_LAUNCH(kD, grid, 64, smem, (hipStream_t) nullptr, view, d_q, nq, d_ids, n_ids, d_out);
+        hipEventRecord(e1, nullptr);
+        hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        best = std::min(best, ms);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(d_q); hipFree(d_out); hipFree(d_ids);
+    *ms_out = best;
+    return IDIST_OK;
+}
+#endif
 
 idist_status idist_distance_batch(const idist_index* idx, const float* queries, uint32_t nq, const uint32_t* ids,
                                   uint32_t n_ids, float* out_dist) {

@@ -129,14 +129,14 @@ __device__ __forceinline__ float fold_chains(float acc, bool has_tail, float tq,
 // one HBM round trip per 8*RIF rows instead of one per 8 rows, and the query fragment of the lane sits in
 // registers (there is one wave per SIMD in this mode, so nothing else would hide the LDS reads).  Same
 // arithmetic, same results.
-template <int NB, int RS, int TAIL, int RIF>
+template <int NB, int RS, int TAIL, int RIF, bool QREGS = true>
 __device__ __forceinline__ void dist_rounds_inflight(const IndexView& ix, const VecView qv, const uint32_t* act_pid,
                                                      uint32_t* act_dist, int na) {
     static_assert(NB >= 0 && RS >= 0 && TAIL >= 0 && RIF >= 1, "compile-time layout only");
     const int lane = lane_id();
     const int g = lane >> 3, j = lane & 7;
     constexpr int NBA = NB > 0 ? NB : 1, RSA = RS > 0 ? RS : 1;
-    constexpr bool QREG = NB <= 12;
+    constexpr bool QREG = QREGS && NB <= 12;
     float4 qf[QREG ? NBA : 1];
     float qr[RSA];
     if constexpr (QREG) {
@@ -271,6 +271,16 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q,
 //   kWalkOverlap  full batches: the same overlaps with 2 rounds in flight and the 8-KB Bloom filter — 12 waves
 //                 per CU stay resident and each keeps twice the bytes in flight (+11 % over classic at C3)
 enum : int { kWalkClassic = 0, kWalkLatency = 1, kWalkOverlap = 2 };
+// A walk code may carry overrides on top of its mode (tuning builds instantiate several):
+//   bits 0-1 mode, bits 4-7 rounds in flight (0 = the mode's default), bit 8 query fragment read from LDS
+//   instead of registers, bits 12-14 waves per SIMD the kernel is compiled for (0 = compiler's choice)
+constexpr int walk_code(int mode, int rif = 0, bool q_lds = false, int waves = 0) {
+    return mode | (rif << 4) | ((q_lds ? 1 : 0) << 8) | (waves << 12);
+}
+constexpr int walk_mode(int code) { return code & 3; }
+constexpr int walk_rif(int code) { return (code >> 4) & 15; }
+constexpr bool walk_q_lds(int code) { return ((code >> 8) & 1) != 0; }
+constexpr int walk_waves(int code) { return (code >> 12) & 7; }
 #ifndef IDIST_RIF9
 #define IDIST_RIF9 4
 #endif
@@ -283,15 +293,17 @@ enum : int { kWalkClassic = 0, kWalkLatency = 1, kWalkOverlap = 2 };
 // rounds in flight: bounded by the VGPRs one row fragment needs (a 300-d fragment is 38 dwords per lane)
 template <int NB, int WALK>
 constexpr int rounds_in_flight() {
-    if (NB < 0 || WALK == kWalkClassic) return 1;
-    if (WALK == kWalkLatency) return NB <= 4 ? 8 : (NB <= 12 ? IDIST_RIF9 : (NB <= 24 ? 2 : 1));
+    if (NB < 0 || walk_mode(WALK) == kWalkClassic) return 1;
+    if (walk_rif(WALK)) return walk_rif(WALK);
+    if (walk_mode(WALK) == kWalkLatency) return NB <= 4 ? 8 : (NB <= 12 ? IDIST_RIF9 : (NB <= 24 ? 2 : 1));
     return NB <= 12 ? IDIST_RIF_OVERLAP : (NB <= 24 ? IDIST_RIF24_OVERLAP : 1);
 }
 template <int NB, int RS, int TAIL, int WALK>
 __device__ __forceinline__ void dist_rounds_walk(const IndexView& ix, const float* q, const uint32_t* act_pid,
                                                  uint32_t* act_dist, int na) {
     constexpr int RIF = rounds_in_flight<NB, WALK>();
-    if constexpr (RIF > 1) dist_rounds_inflight<NB, RS, TAIL, RIF>(ix, natural_view(q, NB), act_pid, act_dist, na);
+    if constexpr (RIF > 1 || (walk_rif(WALK) == 1 && NB >= 0))
+        dist_rounds_inflight<NB, RS, TAIL, RIF, !walk_q_lds(WALK)>(ix, natural_view(q, NB), act_pid, act_dist, na);
     else dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);
 }
 
@@ -434,12 +446,24 @@ __device__ __forceinline__ uint32_t dlog_find(const uint64_t* T, uint32_t pid) {
 }
 
 // ---------------------------------------------------------------------------
-// Visited (core/types.rs:13-59) in HBM: one byte per point, per slot.
+// Visited (core/types.rs:13-59): exact set membership, one BIT per point and resident query slot in HBM.
+//
+// The reference stamps a generation byte per point and clears by bumping the generation (:48-58) — "an
+// optimisation with no observable effect" (SURVEY App. A.13).  A byte per point and slot is 4 GB for 4096
+// slots at 1M points: 8x the page footprint of the bitmap for the same random single-sector updates.  The bitmap
+// has no generation, so `clear` has to zero what was set; the wave remembers WHERE it set bits in a small LDS
+// bitmap over 64-B..512-B blocks of its slot ("dirty blocks") and zeroes exactly those with full-sector stores
+// (no read).  Upper layers (ef = 1) dirty a few dozen blocks, the zero layer most of a 1M-point slot — never
+// more than one streaming pass over n/8 bytes per query.
+//
+// All updates are L2 atomics (`global_atomic_or`): lanes of one wave may share a word, and the returning form is
+// the test-and-set of Visited::insert (:32-40).  No plain load ever reads the bitmap, so the CU's L1 cannot
+// serve a stale copy.  A slot belongs to one wave; slots never share a 64-B sector.
+//
+// In front of it an optional per-wave Bloom filter in LDS (two hashes): it has no false negatives, so "not in
+// the filter" proves the node new — it is marked with the fire-and-forget form of the atomic and goes straight
+// to the distance rounds, while a "maybe" waits for the returning form (the bitmap stays the ground truth).
 // ---------------------------------------------------------------------------
-// In front of it an optional per-wave Bloom filter in LDS (kBloomWords x 32 bits, two hashes): it has no
-// false negatives, so "not in the filter" proves the node was not visited and the HBM byte need not be
-// read — true for ~97 % of the new nodes at ef = 100, i.e. ~3/4 of all visited reads disappear.  A "maybe"
-// falls through to the byte array, which stays the ground truth (writes always happen).
 #ifndef IDIST_BLOOM_LOG2_WORDS
 #define IDIST_BLOOM_LOG2_WORDS 11
 #endif
@@ -450,10 +474,33 @@ constexpr int kBloomWords = 1 << kBloomLog2Words;
 #endif
 constexpr int kBloomLatLog2Words = IDIST_BLOOM_LAT_LOG2_WORDS;   // 8192 words = 32 KB: latency mode (few waves, LDS to spare)
 constexpr int kBloomLatWords = 1 << kBloomLatLog2Words;
+
+// Geometry of one slot: the bitmap is cut into blocks of 2^shift points (>= 512 points = one 64-B sector) such
+// that the dirty-block bitmap fits kDirtyMaxWords dwords of LDS whatever n is.
+constexpr uint32_t kDirtyMaxWords = 1024;                   // 4 KB of LDS: 32768 blocks
+struct VisGeom {
+    uint32_t shift;        // log2(points per block), >= 9
+    uint32_t blocks;       // blocks per slot
+    uint32_t dirty_words;  // LDS dwords of the dirty-block bitmap (multiple of 64: whole wave strides)
+    uint32_t slot_words;   // dwords per slot in HBM (blocks << (shift - 5))
+};
+__host__ __device__ inline VisGeom vis_geometry(uint32_t n) {
+    VisGeom g;
+    g.shift = 9;
+    while ((((uint64_t)n + (1ull << g.shift) - 1) >> g.shift) > (uint64_t)kDirtyMaxWords * 32u) g.shift++;
+    g.blocks = (uint32_t)(((uint64_t)n + (1ull << g.shift) - 1) >> g.shift);
+    if (g.blocks == 0) g.blocks = 1;
+    g.dirty_words = ((g.blocks + 31u) / 32u + 63u) & ~63u;
+    g.slot_words = g.blocks << (g.shift - 5);
+    return g;
+}
+
 struct Visited {
-    uint8_t* store;
+    uint32_t* bits;     // HBM: this slot's bitmap, all-zero whenever no search is in progress on the slot
     uint32_t n;
-    uint32_t gen;       // 1..255
+    uint32_t* dirty;    // LDS: bit b set <=> block b of `bits` may hold a set bit
+    uint32_t shift;     // log2(points per block)
+    uint32_t dirty_words;
     uint32_t* bloom;    // LDS, 1 << blog2 words, or nullptr
     int blog2;          // log2(words)
 };
@@ -468,35 +515,64 @@ __device__ __forceinline__ void bloom_set(const Visited& v, uint32_t pid) {
     atomicOr(&v.bloom[a >> 5], 1u << (a & 31u));
     atomicOr(&v.bloom[b >> 5], 1u << (b & 31u));
 }
-__device__ __forceinline__ void visited_clear(Visited& v) {  // core/types.rs:48-58
+// everything the wave's earlier bitmap updates and zeroing stores did is performed before anything that follows
+__device__ __forceinline__ void visited_drain() {
+#ifndef IDIST_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+// the LDS side of a freshly set bit: its block is dirty, the filter knows the node
+__device__ __forceinline__ void visited_note(const Visited& v, uint32_t pid) {
+    const uint32_t blk = pid >> v.shift;
+    atomicOr(&v.dirty[blk >> 5], 1u << (blk & 31u));
+    if (v.bloom) bloom_set(v, pid);
+}
+// Visited::clear (core/types.rs:48-58): zero the dirty blocks (and the LDS side).  Wave-uniform control flow.
+__device__ __forceinline__ void visited_clear(Visited& v) {
     const int lane = lane_id();
+    wave_sync();                                                // the other lanes' LDS updates are in
     if (v.bloom) {
         uint4* b = reinterpret_cast<uint4*>(v.bloom);
         for (int i = lane; i < (1 << v.blog2) / 4; i += 64) b[i] = make_uint4(0, 0, 0, 0);
-        wave_sync();
     }
-    if (v.gen < 255u) { v.gen += 1u; return; }
-    uint4* p = reinterpret_cast<uint4*>(v.store);
-    const size_t n16 = ((size_t)v.n + 15u) / 16u;   // store is padded to 16 B
-    for (size_t i = lane; i < n16; i += 64) p[i] = make_uint4(0, 0, 0, 0);
-    __threadfence_block();
+    const uint32_t wpb = 1u << (v.shift - 5);                  // dwords per block (>= 16)
+    for (uint32_t w0 = 0; w0 < v.dirty_words; w0 += 64) {
+        const uint32_t mine = v.dirty[w0 + lane];
+        uint64_t nz = __ballot(mine != 0u);
+        if (mine) v.dirty[w0 + lane] = 0u;
+        while (nz) {                                            // one dirty word (32 blocks) per iteration
+            const int src = __builtin_ctzll(nz);
+            nz &= nz - 1ull;
+            const uint32_t m = bcast_u32(mine, src);
+            // two lanes per block: lane >> 1 = bit, lane & 1 = half of the block
+            const uint32_t bit = (uint32_t)lane >> 1;
+            if ((m >> bit) & 1u) {
+                const uint32_t blk = (w0 + (uint32_t)src) * 32u + bit;
+                uint4* p = reinterpret_cast<uint4*>(v.bits + ((size_t)blk << (v.shift - 5)) + (size_t)(lane & 1) * (wpb / 2));
+                for (uint32_t i = 0; i < wpb / 8; i++) p[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+    visited_drain();
     wave_sync();
-    v.gen = 1u;
 }
-// Visited::insert for one lane's pid (core/types.rs:32-40): true if it was new
-__device__ __forceinline__ bool visited_insert(const Visited& v, uint32_t pid) {
-    bool fresh = true;
-    if (!v.bloom || bloom_maybe(v, pid)) fresh = v.store[pid] != (uint8_t)v.gen;
-    if (fresh) {
-        v.store[pid] = (uint8_t)v.gen;
-        if (v.bloom) bloom_set(v, pid);
-    }
-    return fresh;
+// Visited::insert for one lane's pid (core/types.rs:32-40): true if it was new.  `maybe` = the caller could
+// not prove the node new (no filter, or the filter says "maybe"): then the returning atomic decides.
+__device__ __forceinline__ bool visited_test_and_set(const Visited& v, uint32_t pid) {
+    const uint32_t bit = 1u << (pid & 31u);
+    const uint32_t old = atomicOr(&v.bits[pid >> 5], bit);
+    return (old & bit) == 0u;
 }
-// Visited::extend with one pid per lane (core/types.rs:42-46), used by cull
+// Visited::extend with one pid per lane (core/types.rs:42-46; cull) / a node known to be new
 __device__ __forceinline__ void visited_mark(const Visited& v, uint32_t pid) {
-    v.store[pid] = (uint8_t)v.gen;
-    if (v.bloom) bloom_set(v, pid);
+    atomicOr(&v.bits[pid >> 5], 1u << (pid & 31u));            // result unused: fire and forget
+    visited_note(v, pid);
+}
+__device__ __forceinline__ bool visited_insert(const Visited& v, uint32_t pid) {
+    if (v.bloom && !bloom_maybe(v, pid)) { visited_mark(v, pid); return true; }
+    const bool fresh = visited_test_and_set(v, pid);
+    if (fresh) visited_note(v, pid);
+    return fresh;
 }
 
 struct Counters { uint32_t n_dist, n_exp0, n_expU; };
@@ -629,8 +705,8 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     const int lane = lane_id();
     uint32_t guard = 0;
     const bool row_lane = lane < row_stride && lane < links;
-    constexpr bool PFA = LAT != kWalkClassic;   // adjacency requested one expansion ahead
-    constexpr bool OVL = LAT != kWalkClassic;   // visited bytes in flight during the first distance pass
+    constexpr bool PFA = walk_mode(LAT) != kWalkClassic;   // adjacency requested one expansion ahead
+    constexpr bool OVL = walk_mode(LAT) != kWalkClassic;   // visited test-and-set in flight during the first distance pass
     uint32_t pf_pid = kInvalid, pf_row = kInvalid;
     for (;;) {
         const int ci = w_pop(st);                         // :599-604
@@ -681,11 +757,12 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             }
         } else {
             bool sure = false, maybe = false;
-            uint8_t vb = 0;
+            uint32_t vold = 0;
+            const uint32_t vbit = 1u << (nb_pid & 31u);
             if (is_nb) {
                 if (nb_pid >= ix.n) st.status |= kStBadRow;
                 else if (vis.bloom && !bloom_maybe(vis, nb_pid)) sure = true;
-                else { maybe = true; vb = vis.store[nb_pid]; }       // in flight during the first pass
+                else { maybe = true; vold = atomicOr(&vis.bits[nb_pid >> 5], vbit); }   // test-and-set, in flight during the first pass
             }
             if (sure) visited_mark(vis, nb_pid);
             uint32_t my_d = 0;
@@ -699,8 +776,8 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 wave_sync();
                 if (sure) my_d = act_dist[my];
             }
-            const bool late = maybe && vb != (uint8_t)vis.gen;
-            if (late) visited_mark(vis, nb_pid);
+            const bool late = maybe && (vold & vbit) == 0u;
+            if (late) visited_note(vis, nb_pid);
             const uint64_t lm = __ballot(late);
             wave_sync();
             if (lm) {

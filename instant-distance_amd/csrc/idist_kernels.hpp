@@ -92,14 +92,16 @@ struct Smem {
     uint64_t* aux;       // 3*64+1 u64 (build only): news / sel / disc
     uint32_t* act_pid;   // 64
     uint32_t* act_dist;  // 64
+    uint32_t* dirty;     // dirty-block bitmap of the visited set (graph walks only), dirty_words dwords
     uint32_t* bloom;     // kBloomWords / kBloomLatWords, last in the carve-up (graph walks only)
 };
-__host__ __device__ inline size_t smem_bytes(uint32_t stride, uint32_t wcap, bool build, uint32_t bloom_words = kBloomWords) {
-    size_t b = (size_t)stride * 4 * (build ? 2 : 1) + (size_t)wcap * 8 + 2 * 64 * 4 + (size_t)bloom_words * 4;
+__host__ __device__ inline size_t smem_bytes(uint32_t stride, uint32_t wcap, bool build, uint32_t bloom_words = kBloomWords,
+                                             uint32_t dirty_words = 0) {
+    size_t b = (size_t)stride * 4 * (build ? 2 : 1) + (size_t)wcap * 8 + 2 * 64 * 4 + (size_t)(bloom_words + dirty_words) * 4;
     if (build) b += (size_t)(3 * 64 + 8) * 8;
     return b;
 }
-__device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t wcap, bool build) {
+__device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t wcap, bool build, uint32_t dirty_words = 0) {
     Smem s;
     s.q = reinterpret_cast<float*>(base);
     base += (size_t)stride * 4;
@@ -111,7 +113,8 @@ __device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t w
     if (build) base += (size_t)(3 * 64 + 8) * 8;
     s.act_pid = reinterpret_cast<uint32_t*>(base);
     s.act_dist = s.act_pid + 64;
-    s.bloom = s.act_dist + 64;
+    s.dirty = s.act_dist + 64;
+    s.bloom = s.dirty + dirty_words;
     return s;
 }
 
@@ -125,9 +128,8 @@ struct SearchArgs {
     float* out_dist;        // [nq][ef]
     uint32_t* out_count;    // [nq]
     uint32_t* out_counters; // [nq][3] or null
-    uint8_t* visited;       // [slots][vis_stride]
-    size_t vis_stride;
-    uint8_t* gen;           // [slots]
+    uint32_t* visited;      // [slots][vis.slot_words] bitmaps, all-zero between launches
+    VisGeom vis;            // vis_geometry(n)
     uint32_t* next;         // work queue head
     uint32_t* status;
     uint32_t use_bloom;     // LDS Bloom filter in front of the visited bytes
@@ -135,16 +137,23 @@ struct SearchArgs {
 };
 
 // LAT: walk mode (kWalkClassic / kWalkLatency / kWalkOverlap, see search_layer).
+// waves per SIMD a walk code asks the register allocator for (0 = its own choice)
+#ifndef IDIST_WAVES_ATTR
+#define IDIST_WAVES_ATTR(LAT_) \
+    __attribute__((amdgpu_waves_per_eu(walk_waves(LAT_) ? walk_waves(LAT_) : 1, walk_waves(LAT_) ? walk_waves(LAT_) : 8)))
+#endif
 template <int NB, int RS, int TAIL, int LAT = 0>
-__global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) {
+__global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void search_kernel(IndexView ix, SearchArgs a) {
     IDIST_DYN_SMEM(smem_raw);
-    const Smem sm = carve(smem_raw, ix.stride, a.wcap, false);
+    const Smem sm = carve(smem_raw, ix.stride, a.wcap, false, a.vis.dirty_words);
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
-    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot], a.use_bloom ? sm.bloom : nullptr,
-                LAT == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
+    Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words,
+                a.use_bloom ? sm.bloom : nullptr, walk_mode(LAT) == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
     uint32_t status = 0;
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
+    for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
+    visited_clear(vis);                                                // LDS side; the slot's bitmap is clean between launches
     for (;;) {
         uint32_t qi = 0;
         if (lane == 0) qi = atomicAdd(a.next, 1u);
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) 
 
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
         Counters ctr{0, 0, 0};
-        visited_clear(vis);                                            // search.reset(), :357
+        // search.reset(), :357: the visited set was emptied when the slot's previous search ended
         push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr);  // :364
         for (int cur = (int)ix.n_upper;; cur--) {                      // :365
             const bool is_zero = cur == 0;
@@ -197,12 +206,9 @@ __global__ __launch_bounds__(64) void search_kernel(IndexView ix, SearchArgs a) 
             }
         }
         status |= st.status;
-        wave_sync();
+        visited_clear(vis);                                            // leave the slot empty for its next search
     }
-    if (lane == 0) {
-        a.gen[slot] = (uint8_t)vis.gen;
-        if (status) atomicOr(a.status, status);
-    }
+    if (lane == 0 && status) atomicOr(a.status, status);
 }
 
 // ---------------------------------------------------------------------------
@@ -307,9 +313,8 @@ struct BuildArgs {
     uint32_t keep_pruned;
     uint32_t use_bloom;         // LDS Bloom filter in front of the visited bytes (descent)
     uint32_t has_heuristic;     // 0 = Builder::select_heuristic(None): select_simple + sorted splice
-    uint8_t* visited;           // [slots][vis_stride]
-    size_t vis_stride;
-    uint8_t* gen;               // [slots]
+    uint32_t* visited;          // [slots][vis.slot_words] bitmaps, all-zero between launches
+    VisGeom vis;                // vis_geometry(n)
     uint32_t* edge_pid;         // [max_batch*64] neighbour selected by item*64+i
     uint32_t* edge_dist;        // its distance bits
     uint32_t* head;             // [n] inbox head per existing node (edge index), kInvalid = empty
@@ -364,16 +369,18 @@ __device__ __forceinline__ void emit_new_node(const IndexView& ix, const BuildAr
 }
 
 template <int NB, int RS, int TAIL, int LAT = 0>
-__global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArgs a) {
+__global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(IndexView ix, BuildArgs a) {
     IDIST_DYN_SMEM(smem_raw);
-    const Smem sm = carve(smem_raw, ix.stride, a.wcap, true);
+    const Smem sm = carve(smem_raw, ix.stride, a.wcap, true, a.vis.dirty_words);
     uint64_t* sel = sm.aux + 64 + 8;
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
-    Visited vis{a.visited + (size_t)slot * a.vis_stride, ix.n, (uint32_t)a.gen[slot], a.use_bloom ? sm.bloom : nullptr,
-                LAT == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
+    Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words,
+                a.use_bloom ? sm.bloom : nullptr, walk_mode(LAT) == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
     uint32_t status = 0;
     Counters tot{0, 0, 0};
+    for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
+    visited_clear(vis);                                               // LDS side; the slot's bitmap is clean between launches
     for (;;) {
         uint32_t item = 0;
         if (lane == 0) item = atomicAdd(&a.queue[0], 1u);
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
 
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
         uint64_t* dlog = a.dlog + (size_t)item * kDlogCap;
-        visited_clear(vis);                                           // search.reset(), :443
+        // search.reset(), :443: the visited set was emptied when the slot's previous descent ended
         push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, dlog);  // :444
         const int num = a.layer == 0 ? kM2 : kM;                      // :445
         for (int cur = (int)a.top;; cur--) {                          // :447
@@ -420,10 +427,9 @@ __global__ __launch_bounds__(64) void build_insert_kernel(IndexView ix, BuildArg
             emit_new_node(ix, a, item, nw_pid, sel, nsel);
         }
         status |= st.status;
-        wave_sync();
+        visited_clear(vis);                                           // leave the slot empty for its next descent
     }
     if (lane == 0) {
-        a.gen[slot] = (uint8_t)vis.gen;
         if (status) atomicOr(a.status, status);
         if (tot.n_dist | tot.n_exp0 | tot.n_expU) {
             atomicAdd(&a.stats[0], (unsigned long long)tot.n_dist);

@@ -6,7 +6,7 @@
 namespace emu {
 
 State& S() {
-    static State s;
+    static thread_local State s;   // one emulated device context per host thread (sharded searches run in threads)
     return s;
 }
 

@@ -26,6 +26,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define IDIST_WAVES_ATTR(...)   /* register-allocation hint of the device compiler */
 #define __restrict__ __restrict
 
 struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
@@ -191,6 +192,10 @@ static inline hipError_t hipMemcpy2D(void* d, size_t dp, const void* s, size_t s
     return hipSuccess;
 }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+static inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 enum { hipStreamNonBlocking = 1 };

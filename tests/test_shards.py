@@ -1,0 +1,119 @@
+"""Several GPUs behind the C ABI: idist_replicate + idist_search_batch_sharded, and the
+lifetime rules of a search context (Search scratch grows on demand; a context is bound to ONE index).
+
+The test box has one GPU (the emulator: one device), so the replicas land on the devices that exist plus a
+second copy on device 0 — the copies, the per-shard host threads and the block partition are the same code
+whatever the device list is.  Bar: shard-concat == single-GPU result == oracle, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from engines import engine_params
+
+
+@pytest.fixture(params=engine_params())
+def eng(request, engine_loader):
+    return engine_loader(request.param), request.param
+
+
+def S(kind, emu, gpu):
+    return gpu if kind == "gpu" else emu
+
+
+def test_replicate_and_sharded_search_match_single_gpu_and_oracle(eng, oracle):
+    ida, kind = eng
+    from instant_distance_amd import _capi
+
+    rng = np.random.default_rng(5)
+    n, dim, nq = S(kind, 300, 20000), S(kind, 12, 128), S(kind, 23, 1001)
+    pts = rng.random((n, dim), dtype=np.float32)
+    q = rng.random((nq, dim), dtype=np.float32)
+    cfg = oracle.default_config(ef_search=40)
+    oix = oracle.Index.build(pts, cfg)
+    want = oix.search(q)
+    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().ef_search(40))
+    single = h.search_batch(q, ida.Search(), counters=True)
+    pc.check_search_result(single, want)
+    devices = list(range(_capi.lib().device_count())) + [0]          # every GPU there is, plus a second copy on GPU 0
+    reps = h.replicate(devices)
+    assert len(reps) == len(devices)
+    for r, d in zip(reps, devices):
+        assert r.info().device == d and r.info().n == n
+        z, layers = r.into_parts()
+        assert np.array_equal(z, oix.zero) and all(np.array_equal(a, b) for a, b in zip(layers, oix.layers))
+    for shards in (reps, reps[:1], [h] + reps):                      # any mix of replicas (the root is one too)
+        got = ida.Hnsw.search_batch_sharded(shards, [ida.Search() for _ in shards], q, counters=True)
+        pc.check_search_result(got, want)
+    # fewer queries than shards: empty ranges are skipped
+    got = ida.Hnsw.search_batch_sharded([h] + reps, [ida.Search() for _ in range(len(reps) + 1)], q[:2], counters=True)
+    assert np.array_equal(got.pid, want.pid[:2]) and np.array_equal(got.counters, want.counters[:2])
+    # Item.point works on a replica: the host copy of the points is shared
+    s = ida.Search()
+    it = next(iter(reps[-1].search(pts[7], s)))
+    assert it.pid == 7 and it.distance == 0.0 and np.array_equal(it.point, pts[7])
+
+
+def test_sharded_search_rejects_bad_shard_sets(eng, oracle):
+    ida, kind = eng
+    rng = np.random.default_rng(6)
+    pts = rng.random((200, 8), dtype=np.float32)
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder().max_batch(1))
+    other = ida.Hnsw.from_ordered_points(pts[:150], ida.Builder().max_batch(1))
+    s = ida.Search()
+    with pytest.raises(ida.IdistError) as e:                          # one context for two shards: they would race
+        ida.Hnsw.search_batch_sharded([h, h], [s, s], pts[:4])
+    assert e.value.status == 1
+    with pytest.raises(ida.IdistError) as e:                          # not replicas of one index
+        ida.Hnsw.search_batch_sharded([h, other], [ida.Search(), ida.Search()], pts[:4])
+    assert e.value.status == 1
+
+
+def test_context_is_bound_to_its_index_not_to_an_address(eng, oracle):
+    """a context created for index A must be rejected for ANY other index — also one that lives at the
+    address A had (free A, build B: `new` very likely hands the address out again)."""
+    ida, kind = eng
+    from instant_distance_amd import _capi
+
+    L = _capi.lib()
+    rng = np.random.default_rng(7)
+    a = ida.Hnsw.from_ordered_points(rng.random((120, 6), dtype=np.float32), ida.Builder().max_batch(1))
+    ctx = C.c_void_p()
+    L.check(L.idist_search_ctx_new(a._h, 0, C.byref(ctx)))
+    addr_a = a._h.value
+    del a                                                             # frees index A; ctx outlives it
+    seen_same_address = False
+    for _ in range(8):
+        b = ida.Hnsw.from_ordered_points(rng.random((4000, 6), dtype=np.float32), ida.Builder())
+        seen_same_address |= b._h.value == addr_a
+        q = np.zeros((1, 6), dtype=np.float32)
+        pid = np.zeros((1, 100), dtype=np.uint32)
+        dd = np.zeros((1, 100), dtype=np.float32)
+        cnt = np.zeros(1, dtype=np.uint32)
+        st = L.idist_search_batch(b._h, ctx, _capi.f32p(q), 1, _capi.u32p(pid), _capi.f32p(dd), _capi.u32p(cnt), None)
+        assert st == 1 and b"does not belong" in L.idist_last_error()
+        if seen_same_address:
+            break
+        del b
+    L.idist_search_ctx_free(ctx)                                      # freeing a context after its index is fine
+
+
+def test_search_scratch_grows_on_demand(eng, oracle):
+    """Search::default() is cheap (core/lib.rs:767-778, scratch sized on first use :363): a fresh context backs one
+    query slot; batches make it grow; results do not depend on the slot count."""
+    ida, kind = eng
+    rng = np.random.default_rng(8)
+    n, dim = S(kind, 260, 8000), S(kind, 8, 64)
+    pts = rng.random((n, dim), dtype=np.float32)
+    q = rng.random((S(kind, 21, 700), dim), dtype=np.float32)
+    oix = oracle.Index.build(pts, oracle.default_config(ef_search=30))
+    want = oix.search(q)
+    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().ef_search(30))
+    s = ida.Search()                                                  # slots = 0: grows
+    for hi in (1, 3, len(q), 2):
+        got = h.search_batch(q[:hi], s, counters=True)
+        assert np.array_equal(got.pid, want.pid[:hi]) and np.array_equal(got.counters, want.counters[:hi])
+    for slots in (1, 2, 5):                                           # fixed slot counts: fewer slots than queries
+        got = h.search_batch(q, ida.Search(slots), counters=True)
+        pc.check_search_result(got, want)
