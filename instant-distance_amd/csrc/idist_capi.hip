@@ -170,6 +170,8 @@ struct Knobs {
     uint32_t latency_nq = 1024;   // IDIST_LATENCY_NQ: batches up to this many queries run the latency walk (0 = never)
     bool classic = false;         // IDIST_WALK=classic
     bool bloom = true;            // IDIST_BLOOM=0 disables the LDS Bloom filter in front of the visited bitmap
+    uint32_t tab_log2 = 0;        // IDIST_TAB_LOG2=<5..13>: size of the on-chip visited set (test knob: small sets exercise the overflow path)
+    bool vis_bitmap = false;      // IDIST_VISITED=bitmap: search with bitmap + Bloom filter (16 waves per CU) instead of the on-chip set
     int tune = -1;                // IDIST_TUNE=<i> (tuning builds only, -DIDIST_TUNE): i-th experimental walk variant
     static Knobs from_env() {
         Knobs k;
@@ -177,6 +179,8 @@ struct Knobs {
         if (const char* e = getenv("IDIST_LATENCY_NQ")) k.latency_nq = (uint32_t)strtoul(e, nullptr, 10);
         if (const char* e = getenv("IDIST_WALK")) k.classic = e[0] == 'c';
         if (const char* e = getenv("IDIST_BLOOM")) k.bloom = e[0] != '0';
+        if (const char* e = getenv("IDIST_VISITED")) k.vis_bitmap = e[0] == 'b';
+        if (const char* e = getenv("IDIST_TAB_LOG2")) k.tab_log2 = std::min(13u, std::max(5u, (uint32_t)atoi(e)));
         return k;
     }
 };
@@ -658,53 +662,74 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
     return IDIST_OK;
 }
 
+// LDS one wave of the on-chip walk may use: one wave per SIMD, four per CU, out of 160 KiB
+constexpr size_t kOnChipLdsPerWave = 40 * 1024;
+
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
                            uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream) {
     const uint32_t ef = ix->cfg.ef_search;
-    CHK(ensure_slots(ctx, nq, stream));
-    ctx->last_ef = ef;
     SearchArgs a{};
     a.queries = d_q;
     a.nq = nq;
     a.ef = ef;
     a.tie_cap = std::max(tie_capacity(ix->cfg), ctx->tie_cap);
     a.wcap = ef + 64 + a.tie_cap + 8;
+    a.vis = ctx->vis;
+    // Default walk: the visited set lives in LDS (an exact hash set of 2^tab_log2 ids per query, the HBM bitmap only
+    // takes what does not fit), one wave per SIMD with up to 512 registers for rows in flight.  The largest set that
+    // fits a quarter of the CU's LDS next to the query tile and W is used; none fits (huge ef_search) -> bitmap walk.
+    uint32_t tab_log2 = 0;
+    if (!ctx->knobs.vis_bitmap)
+        for (uint32_t l = 13; l >= 10 && !tab_log2; l--)
+            if (smem_bytes(ix->L.stride, a.wcap, false, 1u << l, a.vis.dirty_words) <= kOnChipLdsPerWave) tab_log2 = l;
+    if (tab_log2 && ctx->knobs.tab_log2) tab_log2 = std::min(tab_log2, ctx->knobs.tab_log2);
+    const bool on_chip = tab_log2 != 0;
+    a.tab_log2 = tab_log2;
+    const uint32_t resident = (uint32_t)ix->n_cu * (on_chip ? 4u : 16u);
+    CHK(ensure_slots(ctx, std::min(nq, resident), stream));
+    ctx->last_ef = ef;
     a.out_pid = d_pid;
     a.out_dist = d_dist;
     a.out_count = d_cnt;
     a.out_counters = d_ctr;
     a.visited = ctx->d_visited;
-    a.vis = ctx->vis;
     a.next = ctx->d_next;
     a.status = ctx->d_next + 1;
     a.use_bloom = ctx->knobs.bloom ? 1u : 0u;
-    // narrow batches cannot fill the chip: run the latency variant (same results, overlapped round trips)
-    const bool lat = nq <= ctx->knobs.latency_nq &&
+    // bitmap walk only: narrow batches cannot fill the chip and run its latency variant (same results)
+    const bool lat = !on_chip && nq <= ctx->knobs.latency_nq &&
                      smem_bytes(ix->L.stride, a.wcap, false, kBloomLatWords, a.vis.dirty_words) <= 64 * 1024;
-    const size_t smem = smem_bytes(ix->L.stride, a.wcap, false, lat ? kBloomLatWords : kBloomWords, a.vis.dirty_words);
+    const size_t smem = smem_bytes(ix->L.stride, a.wcap, false, on_chip ? (1u << tab_log2) : (lat ? kBloomLatWords : kBloomWords),
+                                   a.vis.dirty_words);
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_search need %zu B of LDS per wave (> 64 KiB)", smem);
-    const uint32_t grid = std::min(nq, ctx->slots);
+    const uint32_t grid = std::min(std::min(nq, ctx->slots), resident);
     const bool classic = ctx->knobs.classic;
     IndexView view = ix->view();
     HIPCHK(hipMemsetAsync(ctx->d_next, 0, 4, stream));
     const uint32_t slot = (uint32_t)(ctx->n_launch % IDIST_EVENT_RING);
     HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
-#define LAUNCH_SEARCH(NB_, RS_, TAIL_)                                       \
-    {                                                                        \
-        if (lat) {                                                           \
-            auto kS = search_kernel<NB_, RS_, TAIL_, kWalkLatency>;          \
-            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);               \
-        } else if (classic) {                                                \
-            auto kS = search_kernel<NB_, RS_, TAIL_, kWalkClassic>;          \
-            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);               \
-        } else {                                                             \
-            auto kS = search_kernel<NB_, RS_, TAIL_, kWalkOverlap>;          \
-            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);               \
-        }                                                                    \
+#define LAUNCH_SEARCH(NB_, RS_, TAIL_)                                                             \
+    {                                                                                              \
+        if (on_chip && classic) {                                                                  \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>;  \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+        } else if (on_chip) {                                                                      \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true)>;  \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+        } else if (lat) {                                                                          \
+            auto kS = search_kernel<NB_, RS_, TAIL_, kWalkLatency>;                                \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+        } else if (classic) {                                                                      \
+            auto kS = search_kernel<NB_, RS_, TAIL_, kWalkClassic>;                                \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+        } else {                                                                                   \
+            auto kS = search_kernel<NB_, RS_, TAIL_, kWalkOverlap>;                                \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+        }                                                                                          \
     }
 #ifdef IDIST_TUNE
-    // tuning build: full 300-d batches through one of the experimental variants of the overlap walk
-    if (!lat && ctx->knobs.tune >= 0 && ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) {
+    // tuning build: full 300-d batches through one of the experimental variants of the walk
+    if (on_chip && ctx->knobs.tune >= 0 && ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) {
 #define TUNE_CASE(I_, CODE_)                                              \
     case I_: {                                                            \
         auto kS = search_kernel<9, 1, 1, CODE_>;                          \
@@ -712,19 +737,16 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
         break;                                                            \
     }
         switch (ctx->knobs.tune) {
-            TUNE_CASE(0, walk_code(kWalkOverlap, 2, false, 0))    // = production
-            TUNE_CASE(1, walk_code(kWalkOverlap, 2, true, 0))
-            TUNE_CASE(2, walk_code(kWalkOverlap, 2, true, 3))
-            TUNE_CASE(3, walk_code(kWalkOverlap, 3, false, 0))
-            TUNE_CASE(4, walk_code(kWalkOverlap, 3, true, 2))
-            TUNE_CASE(5, walk_code(kWalkOverlap, 4, true, 2))
-            TUNE_CASE(6, walk_code(kWalkOverlap, 1, true, 4))
-            TUNE_CASE(7, walk_code(kWalkOverlap, 1, false, 4))
-            TUNE_CASE(8, walk_code(kWalkOverlap, 4, false, 2))
-            TUNE_CASE(9, walk_code(kWalkOverlap, 2, false, 3))
-            TUNE_CASE(10, walk_code(kWalkOverlap, 8, true, 1))
-            TUNE_CASE(11, walk_code(kWalkOverlap, 6, true, 1))
-            TUNE_CASE(12, walk_code(kWalkOverlap, 8, false, 1))
+            TUNE_CASE(0, walk_code(kWalkOverlap, 0, false, 1, true))    // = production (rif 4, query fragment in registers)
+            TUNE_CASE(1, walk_code(kWalkOverlap, 3, false, 1, true))
+            TUNE_CASE(2, walk_code(kWalkOverlap, 6, false, 1, true))
+            TUNE_CASE(3, walk_code(kWalkOverlap, 8, false, 1, true))
+            TUNE_CASE(4, walk_code(kWalkOverlap, 4, true, 1, true))
+            TUNE_CASE(5, walk_code(kWalkOverlap, 6, true, 1, true))
+            TUNE_CASE(6, walk_code(kWalkOverlap, 8, true, 1, true))
+            TUNE_CASE(7, walk_code(kWalkOverlap, 2, false, 1, true))
+            TUNE_CASE(8, walk_code(kWalkOverlap, 4, false, 0, true))
+            TUNE_CASE(9, walk_code(kWalkOverlap, 5, false, 1, true))
             default: return fail(IDIST_ERR_INVALID_ARG, "IDIST_TUNE=%d: no such variant", ctx->knobs.tune);
         }
 #undef TUNE_CASE

@@ -274,9 +274,11 @@ enum : int { kWalkClassic = 0, kWalkLatency = 1, kWalkOverlap = 2 };
 // A walk code may carry overrides on top of its mode (tuning builds instantiate several):
 //   bits 0-1 mode, bits 4-7 rounds in flight (0 = the mode's default), bit 8 query fragment read from LDS
 //   instead of registers, bits 12-14 waves per SIMD the kernel is compiled for (0 = compiler's choice)
-constexpr int walk_code(int mode, int rif = 0, bool q_lds = false, int waves = 0) {
-    return mode | (rif << 4) | ((q_lds ? 1 : 0) << 8) | (waves << 12);
+//   bit 9 visited set kept on chip (LDS hash set, HBM bitmap only as overflow) instead of bitmap + Bloom filter
+constexpr int walk_code(int mode, int rif = 0, bool q_lds = false, int waves = 0, bool vis_lds = false) {
+    return mode | (rif << 4) | ((q_lds ? 1 : 0) << 8) | ((vis_lds ? 1 : 0) << 9) | (waves << 12);
 }
+constexpr bool walk_vis_lds(int code) { return ((code >> 9) & 1) != 0; }
 constexpr int walk_mode(int code) { return code & 3; }
 constexpr int walk_rif(int code) { return (code >> 4) & 15; }
 constexpr bool walk_q_lds(int code) { return ((code >> 8) & 1) != 0; }
@@ -295,6 +297,7 @@ template <int NB, int WALK>
 constexpr int rounds_in_flight() {
     if (NB < 0 || walk_mode(WALK) == kWalkClassic) return 1;
     if (walk_rif(WALK)) return walk_rif(WALK);
+    if (walk_vis_lds(WALK)) return NB <= 4 ? 8 : (NB <= 12 ? 4 : (NB <= 24 ? 3 : 1));   // one wave per SIMD: registers to spare
     if (walk_mode(WALK) == kWalkLatency) return NB <= 4 ? 8 : (NB <= 12 ? IDIST_RIF9 : (NB <= 24 ? 2 : 1));
     return NB <= 12 ? IDIST_RIF_OVERLAP : (NB <= 24 ? IDIST_RIF24_OVERLAP : 1);
 }
@@ -503,6 +506,14 @@ struct Visited {
     uint32_t dirty_words;
     uint32_t* bloom;    // LDS, 1 << blog2 words, or nullptr
     int blog2;          // log2(words)
+    // On-chip variant: an exact hash set of the visited ids in LDS (open addressing, linear probing, EMPTY = INVALID).
+    // While it has room the HBM bitmap is not touched at all; once `count` reaches `tlimit` the set is frozen for the
+    // rest of the layer ("spill"): lookups still probe it, new ids go to the bitmap.
+    uint32_t* tab = nullptr;   // LDS, tmask + 1 entries, or nullptr
+    uint32_t tmask = 0, tshift = 0, tlimit = 0;   // entries - 1, 32 - log2(entries), entries the set may hold
+    uint32_t count = 0;        // entries in tab (wave-uniform)
+    bool spill = false;        // tab frozen, bitmap in use (wave-uniform)
+    bool dirtied = false;      // the bitmap may hold set bits (wave-uniform)
 };
 __device__ __forceinline__ uint32_t bloom_h1(const Visited& v, uint32_t pid) { return (pid * 0x9E3779B1u) >> (27 - v.blog2); }
 __device__ __forceinline__ uint32_t bloom_h2(const Visited& v, uint32_t pid) { return (pid * 0x85EBCA6Bu + 0xC2B2AE35u) >> (27 - v.blog2); }
@@ -527,7 +538,27 @@ __device__ __forceinline__ void visited_note(const Visited& v, uint32_t pid) {
     atomicOr(&v.dirty[blk >> 5], 1u << (blk & 31u));
     if (v.bloom) bloom_set(v, pid);
 }
-// Visited::clear (core/types.rs:48-58): zero the dirty blocks (and the LDS side).  Wave-uniform control flow.
+__device__ __forceinline__ uint32_t tab_slot(const Visited& v, uint32_t pid) { return (pid * 0x9E3779B1u) >> v.tshift; }
+// insert pid into the LDS set: true if it was new.  Lanes of a wave insert distinct ids concurrently (ds_cmpst).
+__device__ __forceinline__ bool tab_insert(const Visited& v, uint32_t pid) {
+    uint32_t sl = tab_slot(v, pid);
+    for (;;) {
+        const uint32_t old = atomicCAS(&v.tab[sl], kInvalid, pid);
+        if (old == kInvalid) return true;
+        if (old == pid) return false;
+        sl = (sl + 1u) & v.tmask;
+    }
+}
+__device__ __forceinline__ bool tab_find(const Visited& v, uint32_t pid) {
+    uint32_t sl = tab_slot(v, pid);
+    for (;;) {
+        const uint32_t e = v.tab[sl];
+        if (e == pid) return true;
+        if (e == kInvalid) return false;
+        sl = (sl + 1u) & v.tmask;
+    }
+}
+// Visited::clear (core/types.rs:48-58): empty the on-chip set / zero the dirty blocks.  Wave-uniform control flow.
 __device__ __forceinline__ void visited_clear(Visited& v) {
     const int lane = lane_id();
     wave_sync();                                                // the other lanes' LDS updates are in
@@ -535,41 +566,71 @@ __device__ __forceinline__ void visited_clear(Visited& v) {
         uint4* b = reinterpret_cast<uint4*>(v.bloom);
         for (int i = lane; i < (1 << v.blog2) / 4; i += 64) b[i] = make_uint4(0, 0, 0, 0);
     }
-    const uint32_t wpb = 1u << (v.shift - 5);                  // dwords per block (>= 16)
-    for (uint32_t w0 = 0; w0 < v.dirty_words; w0 += 64) {
-        const uint32_t mine = v.dirty[w0 + lane];
-        uint64_t nz = __ballot(mine != 0u);
-        if (mine) v.dirty[w0 + lane] = 0u;
-        while (nz) {                                            // one dirty word (32 blocks) per iteration
-            const int src = __builtin_ctzll(nz);
-            nz &= nz - 1ull;
-            const uint32_t m = bcast_u32(mine, src);
-            // two lanes per block: lane >> 1 = bit, lane & 1 = half of the block
-            const uint32_t bit = (uint32_t)lane >> 1;
-            if ((m >> bit) & 1u) {
-                const uint32_t blk = (w0 + (uint32_t)src) * 32u + bit;
-                uint4* p = reinterpret_cast<uint4*>(v.bits + ((size_t)blk << (v.shift - 5)) + (size_t)(lane & 1) * (wpb / 2));
-                for (uint32_t i = 0; i < wpb / 8; i++) p[i] = make_uint4(0, 0, 0, 0);
+    if (v.tab) {
+        uint4* t = reinterpret_cast<uint4*>(v.tab);
+        for (uint32_t i = lane; i < (v.tmask + 1u) / 4u; i += 64) t[i] = make_uint4(kInvalid, kInvalid, kInvalid, kInvalid);
+        v.count = 0;
+        v.spill = false;
+    }
+    if (!v.tab || v.dirtied) {
+        const uint32_t wpb = 1u << (v.shift - 5);              // dwords per block (>= 16)
+        for (uint32_t w0 = 0; w0 < v.dirty_words; w0 += 64) {
+            const uint32_t mine = v.dirty[w0 + lane];
+            uint64_t nz = __ballot(mine != 0u);
+            if (mine) v.dirty[w0 + lane] = 0u;
+            while (nz) {                                        // one dirty word (32 blocks) per iteration
+                const int src = __builtin_ctzll(nz);
+                nz &= nz - 1ull;
+                const uint32_t m = bcast_u32(mine, src);
+                // two lanes per block: lane >> 1 = bit, lane & 1 = half of the block
+                const uint32_t bit = (uint32_t)lane >> 1;
+                if ((m >> bit) & 1u) {
+                    const uint32_t blk = (w0 + (uint32_t)src) * 32u + bit;
+                    uint4* p = reinterpret_cast<uint4*>(v.bits + ((size_t)blk << (v.shift - 5)) + (size_t)(lane & 1) * (wpb / 2));
+                    for (uint32_t i = 0; i < wpb / 8; i++) p[i] = make_uint4(0, 0, 0, 0);
+                }
             }
         }
+        visited_drain();
+        v.dirtied = false;
     }
-    visited_drain();
     wave_sync();
 }
-// Visited::insert for one lane's pid (core/types.rs:32-40): true if it was new.  `maybe` = the caller could
-// not prove the node new (no filter, or the filter says "maybe"): then the returning atomic decides.
+// Wave-uniform bookkeeping of the on-chip set around one expansion: freeze it before it could fill up
+// (an expansion adds at most 64 ids), count what was added.
+__device__ __forceinline__ void visited_begin(Visited& v, uint32_t n_max = 64u) {
+    if (v.tab && !v.spill && v.count + n_max > v.tlimit) v.spill = true;
+}
+__device__ __forceinline__ void visited_added(Visited& v, uint32_t n_new) {
+    if (!v.tab) return;
+    if (v.spill) { if (n_new) v.dirtied = true; }
+    else v.count += n_new;
+}
+// the returning atomic is the test-and-set of Visited::insert (:32-40)
 __device__ __forceinline__ bool visited_test_and_set(const Visited& v, uint32_t pid) {
     const uint32_t bit = 1u << (pid & 31u);
     const uint32_t old = atomicOr(&v.bits[pid >> 5], bit);
     return (old & bit) == 0u;
 }
-// Visited::extend with one pid per lane (core/types.rs:42-46; cull) / a node known to be new
+// Visited::extend with one pid per lane (core/types.rs:42-46; cull) / a node known to be new.
+// (with the on-chip set the caller brackets it with visited_begin / visited_added like an expansion)
 __device__ __forceinline__ void visited_mark(const Visited& v, uint32_t pid) {
+    if (v.tab) {
+        if (!v.spill) { tab_insert(v, pid); return; }
+        if (tab_find(v, pid)) return;
+    }
     atomicOr(&v.bits[pid >> 5], 1u << (pid & 31u));            // result unused: fire and forget
     visited_note(v, pid);
 }
+// Visited::insert for one lane's pid (core/types.rs:32-40): true if it was new
 __device__ __forceinline__ bool visited_insert(const Visited& v, uint32_t pid) {
-    if (v.bloom && !bloom_maybe(v, pid)) { visited_mark(v, pid); return true; }
+    if (v.tab) {
+        if (!v.spill) return tab_insert(v, pid);
+        if (tab_find(v, pid)) return false;
+    } else if (v.bloom && !bloom_maybe(v, pid)) {
+        visited_mark(v, pid);
+        return true;
+    }
     const bool fresh = visited_test_and_set(v, pid);
     if (fresh) visited_note(v, pid);
     return fresh;
@@ -582,7 +643,9 @@ template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, WState& st, Visited& vis,
                                            uint32_t* act_pid, uint32_t* act_dist, Counters& ctr, uint64_t* dlog = nullptr) {
     const int lane = lane_id();
+    visited_begin(vis);
     if (lane == 0) { act_pid[0] = 0u; visited_mark(vis, 0u); }
+    visited_added(vis, 1u);
     wave_sync();
     dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, 1);
     wave_sync();
@@ -706,7 +769,8 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     uint32_t guard = 0;
     const bool row_lane = lane < row_stride && lane < links;
     constexpr bool PFA = walk_mode(LAT) != kWalkClassic;   // adjacency requested one expansion ahead
-    constexpr bool OVL = walk_mode(LAT) != kWalkClassic;   // visited test-and-set in flight during the first distance pass
+    // visited test-and-set in flight during the first distance pass (bitmap + Bloom filter only: the on-chip set answers at once)
+    constexpr bool OVL = walk_mode(LAT) != kWalkClassic && !walk_vis_lds(LAT);
     uint32_t pf_pid = kInvalid, pf_row = kInvalid;
     for (;;) {
         const int ci = w_pop(st);                         // :599-604
@@ -736,18 +800,20 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         if constexpr (!OVL) {
             // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
             bool fresh = false;
+            visited_begin(vis);
             if (is_nb) {
                 if (nb_pid >= ix.n) st.status |= kStBadRow;
                 else fresh = visited_insert(vis, nb_pid);
             }
             const uint64_t fm = __ballot(fresh);
             const int na = __popcll(fm);
+            visited_added(vis, (uint32_t)na);
             wave_sync();
             if (na) {
                 const int my = __popcll(fm & ((1ull << lane) - 1ull));
                 if (fresh) act_pid[my] = nb_pid;                                        // keeps slot order
                 wave_sync();
-                dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);               // :709-710
+                dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na);     // :709-710
                 wave_sync();
                 ctr.n_dist += (uint32_t)na;
                 uint64_t key = kMaxKey;

@@ -97,6 +97,7 @@ struct Smem {
 };
 __host__ __device__ inline size_t smem_bytes(uint32_t stride, uint32_t wcap, bool build, uint32_t bloom_words = kBloomWords,
                                              uint32_t dirty_words = 0) {
+    wcap = (wcap + 1u) & ~1u;   // keeps everything behind W 16-B aligned
     size_t b = (size_t)stride * 4 * (build ? 2 : 1) + (size_t)wcap * 8 + 2 * 64 * 4 + (size_t)(bloom_words + dirty_words) * 4;
     if (build) b += (size_t)(3 * 64 + 8) * 8;
     return b;
@@ -108,7 +109,7 @@ __device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t w
     s.cq = reinterpret_cast<float*>(base);
     if (build) base += (size_t)stride * 4;
     s.W = reinterpret_cast<uint64_t*>(base);
-    base += (size_t)wcap * 8;
+    base += (size_t)((wcap + 1u) & ~1u) * 8;
     s.aux = reinterpret_cast<uint64_t*>(base);
     if (build) base += (size_t)(3 * 64 + 8) * 8;
     s.act_pid = reinterpret_cast<uint32_t*>(base);
@@ -132,9 +133,18 @@ struct SearchArgs {
     VisGeom vis;            // vis_geometry(n)
     uint32_t* next;         // work queue head
     uint32_t* status;
-    uint32_t use_bloom;     // LDS Bloom filter in front of the visited bytes
+    uint32_t use_bloom;     // LDS Bloom filter in front of the visited bitmap (walks without the on-chip set)
+    uint32_t tab_log2;      // log2(entries) of the on-chip visited set (walks with it)
     uint32_t tie_cap;       // capacity of the tie region (idist_config.tie_capacity)
 };
+// the LDS tail region (after the dirty-block bitmap) holds the Bloom filter or the on-chip visited set
+__device__ __forceinline__ void visited_attach_tab(Visited& v, uint32_t* mem, uint32_t log2_entries) {
+    v.bloom = nullptr;
+    v.tab = mem;
+    v.tmask = (1u << log2_entries) - 1u;
+    v.tshift = 32u - log2_entries;
+    v.tlimit = (7u << log2_entries) / 8u;
+}
 
 // LAT: walk mode (kWalkClassic / kWalkLatency / kWalkOverlap, see search_layer).
 // waves per SIMD a walk code asks the register allocator for (0 = its own choice)
@@ -150,6 +160,7 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void search_kernel(IndexV
     const uint32_t slot = blockIdx.x;
     Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words,
                 a.use_bloom ? sm.bloom : nullptr, walk_mode(LAT) == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
+    if constexpr (walk_vis_lds(LAT)) visited_attach_tab(vis, sm.bloom, a.tab_log2);
     uint32_t status = 0;
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
     for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
@@ -182,7 +193,9 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void search_kernel(IndexV
             search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false);
             w_cull(st);                                                // :377-379
             visited_clear(vis);
+            visited_begin(vis, (uint32_t)st.plen);
             for (int i = lane; i < st.plen; i += 64) visited_mark(vis, (uint32_t)st.W[i]);
+            visited_added(vis, (uint32_t)st.plen);
             wave_sync();
         }
         const int cnt = st.plen < st.ef ? st.plen : st.ef;             // search.iter(), :382
@@ -406,7 +419,9 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
                 search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dlog);
                 w_cull(st);
                 visited_clear(vis);
+                visited_begin(vis, (uint32_t)st.plen);
                 for (int i = lane; i < st.plen; i += 64) visited_mark(vis, (uint32_t)st.W[i]);
+                visited_added(vis, (uint32_t)st.plen);
                 wave_sync();
             } else {                                                  // :458-461
                 search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dlog);

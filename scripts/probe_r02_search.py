@@ -68,29 +68,35 @@ emit(what="algorithmic bytes per launch", bytes=alg)
 del ctxs
 
 # (b) walk variants on the same index
-names = ["rif2 qreg (production)", "rif2 qlds", "rif2 qlds occ3", "rif3 qreg", "rif3 qlds occ2", "rif4 qlds occ2",
-         "rif1 qlds occ4", "rif1 qreg occ4", "rif4 qreg occ2", "rif2 qreg occ3"]
-for slots in (0, 2048, 3072):
-    for i, nm in enumerate(names):
-        os.environ["IDIST_TUNE"] = str(i)
-        s = ida.Search(slots)
-        try:
-            kt = time_ctx(s, 5)
-        except Exception as e:  # noqa: BLE001
-            emit(what="variant", i=i, name=nm, slots=slots, error=repr(e))
-            continue
-        same = bool(torch.equal(outs[0], ref_pid) and torch.equal(outs[1].view(torch.int32), ref_d.view(torch.int32))
-                    and torch.equal(outs[3], ref_ctr))
-        med = float(np.median(kt))
-        emit(what="variant", i=i, name=nm, slots=slots, ms=kt, median=med, TBps=round(alg / med / 1e9, 3), identical=same)
-        del s
+names = ["rif4 qreg (production)", "rif3 qreg", "rif6 qreg", "rif8 qreg", "rif4 qlds", "rif6 qlds", "rif8 qlds", "rif2 qreg",
+         "rif4 qreg, compiler's occupancy", "rif5 qreg"]
+for i, nm in enumerate(names):
+    os.environ["IDIST_TUNE"] = str(i)
+    s = ida.Search()
+    try:
+        kt = time_ctx(s, 5)
+    except Exception as e:  # noqa: BLE001
+        emit(what="variant", i=i, name=nm, error=repr(e))
+        continue
+    same = bool(torch.equal(outs[0], ref_pid) and torch.equal(outs[1].view(torch.int32), ref_d.view(torch.int32))
+                and torch.equal(outs[3], ref_ctr))
+    med = float(np.median(kt))
+    emit(what="variant", i=i, name=nm, ms=kt, median=med, TBps=round(alg / med / 1e9, 3), identical=same)
+    del s
 os.environ.pop("IDIST_TUNE", None)
-os.environ["IDIST_WALK"] = "classic"
-s = ida.Search()
-kt = time_ctx(s, 5)
-emit(what="classic walk", ms=kt, TBps=round(alg / float(np.median(kt)) / 1e9, 3))
-os.environ.pop("IDIST_WALK", None)
-# (c) single query
-s = ida.Search()
-kt = time_ctx(s, 16, 1)
-emit(what="nq=1 latency walk", ms_median=float(np.median(kt)))
+for env, nm in (({"IDIST_VISITED": "bitmap"}, "bitmap + Bloom filter, overlap walk, 16 waves/CU"), ({"IDIST_WALK": "classic"}, "on-chip set, classic walk"),
+                ({"IDIST_TAB_LOG2": "12"}, "on-chip set of 4096 ids, then bitmap")):
+    os.environ.update(env)
+    s = ida.Search()
+    kt = time_ctx(s, 5)
+    same = bool(torch.equal(outs[0], ref_pid) and torch.equal(outs[3], ref_ctr))
+    emit(what=nm, ms=kt, TBps=round(alg / float(np.median(kt)) / 1e9, 3), identical=same)
+    for k in env:
+        os.environ.pop(k)
+    del s
+# (c) narrow batches
+for w in (1, 32, 256, 1024, 4096):
+    s = ida.Search()
+    kt = time_ctx(s, 8, w)
+    emit(what="batch width", nq=w, ms_median=round(float(np.median(kt)), 4), qps=round(w / float(np.median(kt)) * 1e3))
+    del s

@@ -11,18 +11,23 @@ import numpy as np
 
 INVALID = 0xFFFFFFFF
 
-# the graph walk has three modes (idist_device.hpp: classic / latency / overlap), chosen by the batch width
-# (IDIST_LATENCY_NQ) and IDIST_WALK; all must give the reference's results
-SEARCH_VARIANTS = (("overlap", {"IDIST_LATENCY_NQ": "0"}),
-                   ("latency", {"IDIST_LATENCY_NQ": "4000000000"}),
-                   ("classic", {"IDIST_LATENCY_NQ": "0", "IDIST_WALK": "classic"}))
+# Variants of the graph walk (idist_device.hpp): the default keeps the visited set on chip (LDS hash set, HBM bitmap
+# as overflow — forced early with a tiny set); IDIST_VISITED=bitmap selects the bitmap + Bloom-filter walks (classic /
+# latency / overlap by batch width and IDIST_WALK).  All must give the reference's results.
+SEARCH_VARIANTS = (("on-chip", {}),
+                   ("on-chip classic", {"IDIST_WALK": "classic"}),
+                   ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7"}),
+                   ("on-chip, set of 32 ids: bitmap from the start", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}),
+                   ("bitmap overlap", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "0"}),
+                   ("bitmap latency", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "4000000000"}),
+                   ("bitmap classic", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "0", "IDIST_WALK": "classic"}))
 
 
 @contextlib.contextmanager
 def search_variant(env):
     if isinstance(env, str):                     # a bare IDIST_LATENCY_NQ value
         env = {"IDIST_LATENCY_NQ": env}
-    keys = ("IDIST_LATENCY_NQ", "IDIST_WALK")
+    keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)
