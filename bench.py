@@ -120,31 +120,24 @@ def main():
                  "wall_seconds": round(t_build, 3), "ef_construction": 100, "batches": int(st.n_batches),
                  "n_dist": int(st.n_dist), "n_heur_dist": int(st.n_heur_dist), "n_updates": int(st.n_updates),
                  "n_updates_memoised": int(st.n_updates_fast), "n_updates_full": int(st.n_updates_full),
-                 # B_i = B_q(ef_construction, partial graph) + per rewritten neighbour (1+deg) rows + 512 B
-                 # of adjacency r/w (unique rows; pairwise reuse on chip) — what the reference's algorithm touches
-                 "alg_bytes": int(st.n_dist * 4 * dim + st.n_exp0 * 256 + st.n_expU * 128
-                                  + st.n_updates * (65 * 4 * dim + 512) + n * 256)}
-        build["alg_GBps_reference_equivalent"] = round(build["alg_bytes"] / st.seconds / 1e9, 1)
+                 "n_heur_rows": int(st.n_heur_rows)}
+        # Bytes the build's algorithm moves AS EXECUTED HERE: the descents (B_q with ef_construction on the partial
+        # graph), every point row fetched for select_heuristic / the neighbour re-selections (n_heur_rows; pairwise
+        # reuse is on chip, memoised verdicts fetch nothing), and the adjacency rows read + rewritten.
+        ab = int(st.n_dist * 4 * dim + st.n_exp0 * 256 + st.n_expU * 128 + st.n_heur_rows * 4 * dim
+                 + st.n_updates * 512 + n * 256)
+        build["roofline"] = {"bound": "hbm", "achieved": round(ab / st.seconds / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": round(ab / st.seconds / 1e9 / HBM_PEAK_GBPS, 4), "alg_bytes": ab,
+                             "note": "all build kernels together over the build's device time; per-kernel PMC bytes: profiles/"}
     t_rep = 0.0
     replication = "single GPU"
     if world > 1:
         t0 = time.time()
-        ok = torch.ones(1, device=dev)
-        try:
-            hnsw = idd.replicate_index(hnsw, builder, src=0)      # RCCL broadcast into the replicas' device buffers
-            torch.cuda.synchronize()
-            replication = "rank 0 built, RCCL broadcast of points/zero/upper device buffers"
-        except Exception as e:  # noqa: BLE001
-            print(f"[rank {rank}] replicate_index failed: {e!r}", file=sys.stderr, flush=True)
-            ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() == 0:
-            # measurement plumbing only: the build is deterministic, so every rank can rebuild the identical index
-            if rank != 0 or hnsw is None:
-                d_tmp = synth(torch, n, dim, 123456789, dev)
-                hnsw = ida.Hnsw.from_device_points(d_tmp.data_ptr(), n, dim, builder)
-                del d_tmp
-            replication = "FALLBACK: broadcast failed, identical index rebuilt on every rank (deterministic build)"
+        # RCCL broadcast into the replicas' device buffers; a failure fails the run (no silent per-rank rebuild:
+        # that curve would not exercise the replication path)
+        hnsw = idd.replicate_index(hnsw, builder, src=0)
+        torch.cuda.synchronize()
+        replication = "rank 0 built, RCCL broadcast of points/zero/upper device buffers"
         dist.barrier()
         t_rep = time.time() - t0
 
@@ -217,15 +210,20 @@ def main():
         launch_bytes = int((ctr[:, 0] * 4 * dim + ctr[:, 1] * 256 + ctr[:, 2] * 128 + 8 * chosen).sum())
         kernel_ms = float(kt.mean())
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic_r01.json")   # HBM bytes per launch from the committed PMC pass
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("search_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # HBM bytes per launch come from separate `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` passes over this same command
+        # (scripts/profile_bench.sh; PMC passes cannot run inside the timed process) — the committed result is quoted
+        traffic, traffic_source = None, None
+        for tp in ("traffic_r02.json", "traffic_r01.json"):
+            tp = os.path.join(ROOT, "profiles", tp)
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get("search_kernel_hbm_bytes_per_launch")
+                    traffic_source = os.path.relpath(tp, ROOT) + " (separate PMC passes of this command, not this run)"
+                    break
+                except Exception:
+                    traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": "search_kernel", "kernel_ms_avg": round(kernel_ms, 3),
                     "alg_bytes_per_launch": launch_bytes, "alg_bytes_per_query": round(launch_bytes / nq),
                     "n_dist_per_query": round(float(ctr[:, 0].mean()), 1), "n_exp0_per_query": round(float(ctr[:, 1].mean()), 1),
@@ -238,9 +236,18 @@ def main():
                                      outs[2].data_ptr(), outs[3].data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         single = {"gpu_kernel_ms_median": round(float(np.median(search.kernel_times_ms(lat_n))), 4), "queries": lat_n,
-                  "note": "nq = 1 per launch, latency variant of the graph walk; cpu = one oracle thread"}
+                  "note": "nq = 1 per launch (the reference's scalar Hnsw::search); cpu = one oracle thread"}
+        # the C ABI's host-pointer call: queries from host memory, results back to host memory (PCIe inclusive), never `value`
+        q_host = d_q.cpu().numpy()
+        hnsw.search_batch(q_host, search)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            res_host = hnsw.search_batch(q_host, search, counters=True)
+        pcie = {"qps": round(nq * 3 / (time.perf_counter() - t0), 1),
+                "note": f"idist_search_batch with host pointers: {nq * dim * 4 >> 20} MB of queries in, {nq * chosen * 8 >> 20} MB of results out per call, pageable memory"}
         run(chosen, outs)                      # restore the full-batch outputs the checks below read
         torch.cuda.synchronize()
+        assert np.array_equal(res_host.pid, outs[0].cpu().numpy().astype(np.uint32))
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -259,6 +266,9 @@ def main():
             for _ in range(3):
                 t0 = time.perf_counter(); ores = oix.search(q_h[:sample], threads=cores); tc = min(tc, time.perf_counter() - t0)
             same = bool(np.array_equal(ores.pid, outs[0][:sample].cpu().numpy().astype(np.uint32)))
+            same_all = bool(same and np.array_equal(ores.dist.view(np.uint32), outs[1][:sample].cpu().numpy().view(np.uint32))
+                            and np.array_equal(ores.count, outs[2][:sample].cpu().numpy().astype(np.uint32))
+                            and np.array_equal(ores.counters, outs[3][:sample].cpu().numpy().astype(np.uint32)))
             t0 = time.perf_counter(); oix.search(q_h[:200], threads=1)
             single["cpu_ms_per_query_one_thread"] = round((time.perf_counter() - t0) / min(200, nq) * 1e3, 4)
             # build baseline: the oracle's threaded build (per-layer parallel-for + per-node locks, the rayon path of
@@ -273,7 +283,8 @@ def main():
                    "sample": f"first {sample} of the {nq} queries, same graph, ef_search={chosen}, {cores} threads = the "
                              f"container's CPU quota ({os.cpu_count()} logical CPUs visible) "
                              "(C oracle = restated reference, not the Rust crate)",
-                   "seconds": round(tc, 2), "ids_identical_to_gpu": same}
+                   "seconds": round(tc, 2), "ids_identical_to_gpu": same,
+                   "ids_distance_bits_counts_and_work_counters_identical_to_gpu": same_all}
 
         out = {"metric": "queries/sec @ recall@10>=0.95, 1Mx300-d f32; index build points/sec",
                "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -286,7 +297,7 @@ def main():
                           "recall_target_met": bool(recall >= args.recall_target), "recall_queries": gtq,
                           "ef_sweep_recall": sweep, "parallelism": f"query-shard x{world}, index replicated",
                           "replication": replication, "replicate_seconds": round(t_rep, 3)},
-               "build": build, "roofline": roofline, "cpu_baseline": cpu, "single_query": single}
+               "build": build, "roofline": roofline, "cpu_baseline": cpu, "single_query": single, "pcie_inclusive": pcie}
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 2)
         print(json.dumps(out), flush=True)

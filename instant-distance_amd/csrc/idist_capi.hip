@@ -664,6 +664,9 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
 
 // LDS one wave of the on-chip walk may use: one wave per SIMD, four per CU, out of 160 KiB
 constexpr size_t kOnChipLdsPerWave = 40 * 1024;
+// A search visits ~53 * ef_search + 600 nodes (C3); the 8192-id set is frozen at 7168.  Beyond ef_search ~ 200 most of a
+// walk would run on the overflow path, where 16 bitmap waves per CU are faster (profiles/probe_r02_search_onchip_visited.jsonl)
+constexpr uint32_t kOnChipMaxEf = 192;
 
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
                            uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream) {
@@ -679,7 +682,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // takes what does not fit), one wave per SIMD with up to 512 registers for rows in flight.  The largest set that
     // fits a quarter of the CU's LDS next to the query tile and W is used; none fits (huge ef_search) -> bitmap walk.
     uint32_t tab_log2 = 0;
-    if (!ctx->knobs.vis_bitmap)
+    if (!ctx->knobs.vis_bitmap && (ef <= kOnChipMaxEf || ctx->knobs.tab_log2))
         for (uint32_t l = 13; l >= 10 && !tab_log2; l--)
             if (smem_bytes(ix->L.stride, a.wcap, false, 1u << l, a.vis.dirty_words) <= kOnChipLdsPerWave) tab_log2 = l;
     if (tab_log2 && ctx->knobs.tab_log2) tab_log2 = std::min(tab_log2, ctx->knobs.tab_log2);

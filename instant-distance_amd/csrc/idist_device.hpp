@@ -510,7 +510,7 @@ struct Visited {
     // While it has room the HBM bitmap is not touched at all; once `count` reaches `tlimit` the set is frozen for the
     // rest of the layer ("spill"): lookups still probe it, new ids go to the bitmap.
     uint32_t* tab = nullptr;   // LDS, tmask + 1 entries, or nullptr
-    uint32_t tmask = 0, tshift = 0, tlimit = 0;   // entries - 1, 32 - log2(entries), entries the set may hold
+    uint32_t tmask = 0, tshift = 0, tlimit = 0;   // buckets - 1, 32 - log2(buckets), ids the set may hold before it is frozen
     uint32_t count = 0;        // entries in tab (wave-uniform)
     bool spill = false;        // tab frozen, bitmap in use (wave-uniform)
     bool dirtied = false;      // the bitmap may hold set bits (wave-uniform)
@@ -538,24 +538,32 @@ __device__ __forceinline__ void visited_note(const Visited& v, uint32_t pid) {
     atomicOr(&v.dirty[blk >> 5], 1u << (blk & 31u));
     if (v.bloom) bloom_set(v, pid);
 }
-__device__ __forceinline__ uint32_t tab_slot(const Visited& v, uint32_t pid) { return (pid * 0x9E3779B1u) >> v.tshift; }
-// insert pid into the LDS set: true if it was new.  Lanes of a wave insert distinct ids concurrently (ds_cmpst).
+// The set is cut into buckets of four ids (one ds_read_b128): a lookup reads whole buckets from the id's home bucket
+// on, an insert claims the first empty entry of the first bucket that has one (ds_cmpst; lanes of a wave insert
+// distinct ids concurrently, the loser of a race reads the bucket again).  Buckets fill front to back and never
+// lose an entry before the next clear, so "this bucket has an empty entry" ends a lookup: the id is not in the set.
+__device__ __forceinline__ uint32_t tab_bucket(const Visited& v, uint32_t pid) { return (pid * 0x9E3779B1u) >> v.tshift; }
+// insert pid into the LDS set: true if it was new
 __device__ __forceinline__ bool tab_insert(const Visited& v, uint32_t pid) {
-    uint32_t sl = tab_slot(v, pid);
+    uint32_t b = tab_bucket(v, pid);
     for (;;) {
-        const uint32_t old = atomicCAS(&v.tab[sl], kInvalid, pid);
+        const uint4 e = *reinterpret_cast<const uint4*>(v.tab + 4u * b);
+        if (e.x == pid || e.y == pid || e.z == pid || e.w == pid) return false;
+        const int k = e.x == kInvalid ? 0 : (e.y == kInvalid ? 1 : (e.z == kInvalid ? 2 : (e.w == kInvalid ? 3 : 4)));
+        if (k == 4) { b = (b + 1u) & v.tmask; continue; }
+        const uint32_t old = atomicCAS(&v.tab[4u * b + (uint32_t)k], kInvalid, pid);
         if (old == kInvalid) return true;
         if (old == pid) return false;
-        sl = (sl + 1u) & v.tmask;
+        // another lane claimed the entry (a different id: a row never holds duplicates): look at the bucket again
     }
 }
 __device__ __forceinline__ bool tab_find(const Visited& v, uint32_t pid) {
-    uint32_t sl = tab_slot(v, pid);
+    uint32_t b = tab_bucket(v, pid);
     for (;;) {
-        const uint32_t e = v.tab[sl];
-        if (e == pid) return true;
-        if (e == kInvalid) return false;
-        sl = (sl + 1u) & v.tmask;
+        const uint4 e = *reinterpret_cast<const uint4*>(v.tab + 4u * b);
+        if (e.x == pid || e.y == pid || e.z == pid || e.w == pid) return true;
+        if (e.w == kInvalid) return false;                      // buckets fill front to back
+        b = (b + 1u) & v.tmask;
     }
 }
 // Visited::clear (core/types.rs:48-58): empty the on-chip set / zero the dirty blocks.  Wave-uniform control flow.
@@ -568,7 +576,7 @@ __device__ __forceinline__ void visited_clear(Visited& v) {
     }
     if (v.tab) {
         uint4* t = reinterpret_cast<uint4*>(v.tab);
-        for (uint32_t i = lane; i < (v.tmask + 1u) / 4u; i += 64) t[i] = make_uint4(kInvalid, kInvalid, kInvalid, kInvalid);
+        for (uint32_t i = lane; i <= v.tmask; i += 64) t[i] = make_uint4(kInvalid, kInvalid, kInvalid, kInvalid);
         v.count = 0;
         v.spill = false;
     }

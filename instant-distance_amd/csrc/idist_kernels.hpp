@@ -141,8 +141,8 @@ struct SearchArgs {
 __device__ __forceinline__ void visited_attach_tab(Visited& v, uint32_t* mem, uint32_t log2_entries) {
     v.bloom = nullptr;
     v.tab = mem;
-    v.tmask = (1u << log2_entries) - 1u;
-    v.tshift = 32u - log2_entries;
+    v.tmask = (1u << (log2_entries - 2u)) - 1u;     // buckets of four ids
+    v.tshift = 32u - (log2_entries - 2u);
     v.tlimit = (7u << log2_entries) / 8u;
 }
 

@@ -100,3 +100,31 @@ for w in (1, 32, 256, 1024, 4096):
     kt = time_ctx(s, 8, w)
     emit(what="batch width", nq=w, ms_median=round(float(np.median(kt)), 4), qps=round(w / float(np.median(kt)) * 1e3))
     del s
+# (d) ef sweep: on-chip set (spills to the bitmap beyond ~7k visited ids) vs bitmap walk
+nd = ref_ctr[:, 0].cpu().numpy()
+emit(what="n_dist per query at ef=100", mean=float(nd.mean()), p50=int(np.percentile(nd, 50)), p90=int(np.percentile(nd, 90)),
+     p99=int(np.percentile(nd, 99)), max=int(nd.max()), over_7168=int((nd > 7168).sum()))
+for ef in (100, 128, 160, 200, 400):
+    h.set_ef_search(ef)
+    o2 = (torch.empty(nq, ef, dtype=torch.int32, device=dev), torch.empty(nq, ef, dtype=torch.float32, device=dev),
+          torch.empty(nq, dtype=torch.int32, device=dev), torch.empty(nq, 3, dtype=torch.int32, device=dev))
+    row = {"what": "ef sweep", "ef": ef}
+    for env, nm in (({}, "on_chip"), ({"IDIST_VISITED": "bitmap"}, "bitmap")):
+        os.environ.update(env)
+        s = ida.Search()
+        for _ in range(4):
+            h.search_batch_device(s, d_q.data_ptr(), nq, o2[0].data_ptr(), o2[1].data_ptr(), o2[2].data_ptr(), o2[3].data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        s.check_status()
+        row[nm + "_ms"] = round(float(np.median(s.kernel_times_ms(3))), 3)
+        row[nm + "_n_dist"] = float(o2[3][:, 0].float().mean().item())
+        for k in env:
+            os.environ.pop(k)
+        del s
+    emit(**row)
+h.set_ef_search(100)
+os.environ["IDIST_VISITED"] = "bitmap"
+s = ida.Search()
+emit(what="nq=1, bitmap latency walk", ms_median=round(float(np.median(time_ctx(s, 16, 1))), 4))
+os.environ.pop("IDIST_VISITED")
