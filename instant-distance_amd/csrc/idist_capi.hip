@@ -303,6 +303,9 @@ uint32_t default_slots(const idist_index* ix) {
     return (uint32_t)std::max<size_t>(s, 1);
 }
 
+// LDS one wave of the on-chip walk may use: one wave per SIMD, four per CU, out of 160 KiB
+constexpr size_t kOnChipLdsPerWave = 40 * 1024;
+
 thread_local uint32_t g_tie_cap_msg = kTieCap;
 uint32_t tie_capacity(const idist_config& cfg) { return g_tie_cap_msg = cfg.tie_capacity ? cfg.tie_capacity : (uint32_t)kTieCap; }
 
@@ -324,17 +327,21 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     const uint32_t top = ix->n_upper;
     // a step never holds more than 1/32 of the points already inserted, so scratch is sized by that
     const uint32_t cap = std::min<uint32_t>(cfg.max_batch == 0 ? 8192u : cfg.max_batch, std::max<uint32_t>(1u, n / 32u));
-    const uint32_t slots_max = default_slots(ix);
-    const uint32_t slots = std::min(cap, slots_max);
+    // the descents keep their visited set on chip, one wave per SIMD (4 per CU), like the search walk
+    const uint32_t slots = std::min(cap, (uint32_t)ix->n_cu * 4u);
     const VisGeom vg = vis_geometry(n);
     const Knobs knobs = Knobs::from_env();
     const uint32_t tie_cap = tie_capacity(cfg);
     const uint32_t wcap = cfg.ef_construction + 64 + tie_cap + 64;
-    const size_t smem = smem_bytes(ix->L.stride, wcap, true, kBloomWords, vg.dirty_words);
-    if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave (> 64 KiB)", smem);
-    // steps too narrow to fill the chip (the early graph, max_batch = 1) run the latency variant of the descent
-    const size_t smem_lat = smem_bytes(ix->L.stride, wcap, true, kBloomLatWords, vg.dirty_words);
-    const uint32_t lat_nq = smem_lat <= 64 * 1024 ? knobs.latency_nq : 0u;
+    // the largest on-chip set that leaves room for four waves per CU; if W alone is too big for that, the largest that fits at all
+    uint32_t tab_log2 = 0;
+    for (uint32_t l = 13; l >= 8 && !tab_log2; l--)
+        if (smem_bytes(ix->L.stride, wcap, true, 1u << l, vg.dirty_words) <= kOnChipLdsPerWave) tab_log2 = l;
+    for (uint32_t l = 13; l >= 8 && !tab_log2; l--)
+        if (smem_bytes(ix->L.stride, wcap, true, 1u << l, vg.dirty_words) <= 64 * 1024) tab_log2 = l;
+    if (!tab_log2) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need more than 64 KiB of LDS per wave");
+    if (knobs.tab_log2) tab_log2 = std::max(8u, std::min(tab_log2, knobs.tab_log2));
+    const size_t smem = smem_bytes(ix->L.stride, wcap, true, 1u << tab_log2, vg.dirty_words);
 
     // step B tile: as many selected rows on chip as fit 64 KiB of LDS next to 8 staging slots
     uint32_t rt = 8;
@@ -354,7 +361,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
     uint32_t* d_small = nullptr;           // [0] n_touched, [1..5] queue (A, B, n_slow, B2, A2), [6] status
-    uint64_t *d_wbuf = nullptr, *d_dlog = nullptr;
+    uint64_t *d_wbuf = nullptr, *d_dlog_log = nullptr;
+    uint32_t *d_dlog_pid = nullptr, *d_dlog_dist = nullptr;
     uint32_t* d_wcount = nullptr;
     uint32_t *d_row_nsel = nullptr, *d_slow = nullptr, *d_nbr_aux = nullptr;
     unsigned long long* d_stats = nullptr; // [8]
@@ -369,8 +377,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     bool pipe = cap > 1 && cfg.has_heuristic;
     if (const char* e = getenv("IDIST_BUILD_PIPELINE")) pipe = pipe && e[0] != '0';
     // the descents (8-12 waves per CU saturate their HBM stream) leave wave slots and LDS to the other stream
-    uint32_t a_waves = 10;
-    if (const char* e = getenv("IDIST_BUILD_A_WAVES")) a_waves = std::max(1, atoi(e));
+    uint32_t a_waves = 3;
+    if (const char* e = getenv("IDIST_BUILD_A_WAVES")) a_waves = std::min(4, std::max(1, atoi(e)));
     uint32_t* d_zero2 = nullptr;
     hipStream_t s1 = nullptr, s2 = nullptr;
     hipEvent_t evA[2] = {nullptr, nullptr}, evS[2] = {nullptr, nullptr};
@@ -379,7 +387,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         if (s1) hipStreamDestroy(s1);
         if (s2) hipStreamDestroy(s2);
         for (int i = 0; i < 2; i++) { if (evA[i]) hipEventDestroy(evA[i]); if (evS[i]) hipEventDestroy(evS[i]); }
-        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount); hipFree(d_dlog);
+        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount); hipFree(d_dlog_log); hipFree(d_dlog_pid); hipFree(d_dlog_dist);
         hipFree(d_vis); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
         if (e0) hipEventDestroy(e0);
@@ -405,7 +413,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     const size_t np = pipe ? 2 : 1;       // step-A outputs are double-buffered in the pipelined schedule
     BCHK(hipMalloc((void**)&d_wbuf, np * cap * cfg.ef_construction * 8));
     BCHK(hipMalloc((void**)&d_wcount, np * cap * 4));
-    BCHK(hipMalloc((void**)&d_dlog, np * cap * kDlogCap * 8));
+    const size_t dl_n = cfg.has_heuristic ? (np * cap) << tab_log2 : 64;   // the simple splice looks nothing up
+    BCHK(hipMalloc((void**)&d_dlog_log, dl_n * 8));
+    BCHK(hipMalloc((void**)&d_dlog_pid, dl_n * 4));
+    BCHK(hipMalloc((void**)&d_dlog_dist, dl_n * 4));
     if (pipe) {
         BCHK(hipMalloc((void**)&d_zero2, (size_t)n * IDIST_M2 * 4));
         BCHK(hipMemset(d_zero2, 0xFF, (size_t)n * IDIST_M2 * 4));
@@ -450,7 +461,11 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     a.queue = d_small + 1;
     a.n_slow = d_small + 3;      // == &queue[2]
     a.status = d_small + 6;
-    a.dlog = d_dlog;
+    a.dlog_log = d_dlog_log;
+    a.dlog_pid = d_dlog_pid;
+    a.dlog_dist = d_dlog_dist;
+    a.tab_log2 = tab_log2;
+    a.use_dlog = getenv("IDIST_BUILD_NO_DLOG") ? 0u : 1u;
     a.wbuf = d_wbuf;
     a.wcount = d_wcount;
     a.rt2 = rt2;
@@ -500,14 +515,15 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
                 viewA.zero = zbuf[(k - lag) & 1u];
                 viewS.zero = zbuf[par];
                 aA.queue = d_small + 1;
-                aA.dlog = d_dlog + (size_t)par * cap * kDlogCap;
+                aA.dlog_log = d_dlog_log + (((size_t)par * cap) << tab_log2);
+                aA.dlog_pid = d_dlog_pid + (((size_t)par * cap) << tab_log2);
+                aA.dlog_dist = d_dlog_dist + (((size_t)par * cap) << tab_log2);
                 aA.wbuf = d_wbuf + (size_t)par * cap * cfg.ef_construction;
                 aA.wcount = d_wcount + (size_t)par * cap;
                 BCHK(hipMemsetAsync(d_small, 0, 8, sA));                  // step A queue head
             } else {
                 BCHK(hipMemsetAsync(d_small, 0, 24, sA));                 // n_touched, queue heads, n_slow
             }
-            BCHK(hipMemsetAsync(aA.dlog, 0xFF, (size_t)B * kDlogCap * 8, sA));   // empty distance logs
             const uint32_t gridA = std::min(B, pipe ? std::min<uint32_t>(slots, (uint32_t)ix->n_cu * a_waves) : slots);
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
             const uint32_t gridS = std::min<uint32_t>(gridB, (uint32_t)ix->n_cu * 6);
@@ -519,15 +535,13 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
             af.efc = no_fast ? 0u : cfg.ef_construction;                  // efc = 0 makes the fast kernel defer everything
 #define LAUNCH_BUILD(NB_, RS_, TAIL_)                                                              \
     {                                                                                              \
-        auto kA = build_insert_kernel<NB_, RS_, TAIL_, kWalkClassic>;                              \
-        auto kAo = build_insert_kernel<NB_, RS_, TAIL_, kWalkOverlap>;                             \
-        auto kAl = build_insert_kernel<NB_, RS_, TAIL_, kWalkLatency>;                             \
+        auto kA = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>; \
+        auto kAo = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true)>; \
         auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
         auto kA2 = build_select_kernel<NB_, RS_, TAIL_>;                                           \
-        if (B <= lat_nq) { IDIST_LAUNCH(kAl, gridA, 64, smem_lat, sA, viewA, aA); }                \
-        else if (classic) { IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA); }                    \
+        if (classic) { IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA); }                         \
         else { IDIST_LAUNCH(kAo, gridA, 64, smem, sA, viewA, aA); }                                \
         if (pipe) {                                                                                \
             BCHK(hipEventRecord(evA[par], s1));                                                    \
@@ -662,8 +676,6 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
     return IDIST_OK;
 }
 
-// LDS one wave of the on-chip walk may use: one wave per SIMD, four per CU, out of 160 KiB
-constexpr size_t kOnChipLdsPerWave = 40 * 1024;
 // A search visits ~53 * ef_search + 600 nodes (C3); the 8192-id set is frozen at 7168.  Beyond ef_search ~ 200 most of a
 // walk would run on the overflow path, where 16 bitmap waves per CU are faster (profiles/probe_r02_search_onchip_visited.jsonl)
 constexpr uint32_t kOnChipMaxEf = 192;

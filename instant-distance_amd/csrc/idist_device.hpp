@@ -419,36 +419,6 @@ __device__ __forceinline__ void w_cull(WState& st) {
 }
 
 // ---------------------------------------------------------------------------
-// Distance log of one insertion (build only): every distance the descent computes is remembered in a
-// small open-addressing table (key = dist_bits << 32 | pid) so that the neighbour re-selection of
-// step B can look d(new, r) up instead of gathering row r again.  A miss is always legal (the caller
-// recomputes), so a full table just drops entries.
-// ---------------------------------------------------------------------------
-constexpr uint32_t kDlogBits = 14;                     // 16384 slots (128 KB) per insertion in flight
-constexpr uint32_t kDlogCap = 1u << kDlogBits;
-constexpr uint64_t kDlogEmpty = 0xFFFFFFFFFFFFFFFFull;
-constexpr uint32_t kDlogMiss = 0xFFFFFFFFu;            // never a canonical distance pattern
-__device__ __forceinline__ uint32_t dlog_slot(uint32_t pid) { return (pid * 0x9E3779B1u) >> (32 - kDlogBits); }
-__device__ __forceinline__ void dlog_insert(uint64_t* T, uint64_t key) {
-    uint32_t sl = dlog_slot((uint32_t)key);
-    for (int probe = 0; probe < 32; probe++) {
-        const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(T + sl), kDlogEmpty, key);
-        if (old == kDlogEmpty || (uint32_t)old == (uint32_t)key) return;
-        sl = (sl + 1) & (kDlogCap - 1);
-    }
-}
-__device__ __forceinline__ uint32_t dlog_find(const uint64_t* T, uint32_t pid) {
-    uint32_t sl = dlog_slot(pid);
-    for (int probe = 0; probe < 32; probe++) {
-        const uint64_t e = T[sl];
-        if (e == kDlogEmpty) return kDlogMiss;
-        if ((uint32_t)e == pid) return (uint32_t)(e >> 32);
-        sl = (sl + 1) & (kDlogCap - 1);
-    }
-    return kDlogMiss;
-}
-
-// ---------------------------------------------------------------------------
 // Visited (core/types.rs:13-59): exact set membership, one BIT per point and resident query slot in HBM.
 //
 // The reference stamps a generation byte per point and clears by bumping the generation (:48-58) — "an
@@ -543,17 +513,17 @@ __device__ __forceinline__ void visited_note(const Visited& v, uint32_t pid) {
 // distinct ids concurrently, the loser of a race reads the bucket again).  Buckets fill front to back and never
 // lose an entry before the next clear, so "this bucket has an empty entry" ends a lookup: the id is not in the set.
 __device__ __forceinline__ uint32_t tab_bucket(const Visited& v, uint32_t pid) { return (pid * 0x9E3779B1u) >> v.tshift; }
-// insert pid into the LDS set: true if it was new
-__device__ __forceinline__ bool tab_insert(const Visited& v, uint32_t pid) {
+// insert pid into the LDS set: its index if it was new, -1 if it was there already
+__device__ __forceinline__ int tab_insert(const Visited& v, uint32_t pid) {
     uint32_t b = tab_bucket(v, pid);
     for (;;) {
         const uint4 e = *reinterpret_cast<const uint4*>(v.tab + 4u * b);
-        if (e.x == pid || e.y == pid || e.z == pid || e.w == pid) return false;
+        if (e.x == pid || e.y == pid || e.z == pid || e.w == pid) return -1;
         const int k = e.x == kInvalid ? 0 : (e.y == kInvalid ? 1 : (e.z == kInvalid ? 2 : (e.w == kInvalid ? 3 : 4)));
         if (k == 4) { b = (b + 1u) & v.tmask; continue; }
         const uint32_t old = atomicCAS(&v.tab[4u * b + (uint32_t)k], kInvalid, pid);
-        if (old == kInvalid) return true;
-        if (old == pid) return false;
+        if (old == kInvalid) return (int)(4u * b) + k;
+        if (old == pid) return -1;
         // another lane claimed the entry (a different id: a row never holds duplicates): look at the bucket again
     }
 }
@@ -624,16 +594,18 @@ __device__ __forceinline__ bool visited_test_and_set(const Visited& v, uint32_t 
 // (with the on-chip set the caller brackets it with visited_begin / visited_added like an expansion)
 __device__ __forceinline__ void visited_mark(const Visited& v, uint32_t pid) {
     if (v.tab) {
-        if (!v.spill) { tab_insert(v, pid); return; }
+        if (!v.spill) { (void)tab_insert(v, pid); return; }
         if (tab_find(v, pid)) return;
     }
     atomicOr(&v.bits[pid >> 5], 1u << (pid & 31u));            // result unused: fire and forget
     visited_note(v, pid);
 }
-// Visited::insert for one lane's pid (core/types.rs:32-40): true if it was new
-__device__ __forceinline__ bool visited_insert(const Visited& v, uint32_t pid) {
+// Visited::insert for one lane's pid (core/types.rs:32-40): true if it was new; tab_idx = where it sits in the on-chip
+// set (-1: not there)
+__device__ __forceinline__ bool visited_insert(const Visited& v, uint32_t pid, int& tab_idx) {
+    tab_idx = -1;
     if (v.tab) {
-        if (!v.spill) return tab_insert(v, pid);
+        if (!v.spill) { tab_idx = tab_insert(v, pid); return tab_idx >= 0; }
         if (tab_find(v, pid)) return false;
     } else if (v.bloom && !bloom_maybe(v, pid)) {
         visited_mark(v, pid);
@@ -644,12 +616,90 @@ __device__ __forceinline__ bool visited_insert(const Visited& v, uint32_t pid) {
     return fresh;
 }
 
+// ---------------------------------------------------------------------------
+// Distance log of one insertion (build only): the neighbour re-selection of step B needs d(new, r) for the
+// members r of the rows the new point chose — distances its own descent already computed.  They are handed over
+// through HBM without a single read-modify-write: while it walks, the wave APPENDS (distance, index of the id in
+// its on-chip visited set) pairs to a per-insertion log — contiguous 8-B stores — and when the descent is over it
+// publishes (a) the on-chip set itself (ids, one coalesced pass) and (b) the distances scattered to the same
+// indices, in one burst.  Step B then probes the published id array exactly like the on-chip set (dlog_find).
+// Only the last layer's distances survive (the set is emptied at every layer transition), ids that went to the
+// overflow bitmap are not logged: a miss is always legal, the caller recomputes.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kDlogMiss = 0xFFFFFFFFu;            // never a canonical distance pattern
+struct DistLog {
+    uint64_t* log;      // HBM [ids the set holds]: dist_bits << 32 | index in the set; nullptr = nothing is logged
+    uint32_t n;         // entries (wave-uniform)
+};
+// index of pid in the on-chip set, -1 if it is not there
+__device__ __forceinline__ int tab_index(const Visited& v, uint32_t pid) {
+    uint32_t b = tab_bucket(v, pid);
+    for (;;) {
+        const uint4 e = *reinterpret_cast<const uint4*>(v.tab + 4u * b);
+        if (e.x == pid) return (int)(4u * b);
+        if (e.y == pid) return (int)(4u * b + 1u);
+        if (e.z == pid) return (int)(4u * b + 2u);
+        if (e.w == pid) return (int)(4u * b + 3u);
+        if (e.w == kInvalid) return -1;
+        b = (b + 1u) & v.tmask;
+    }
+}
+// wave-collective: lanes with idx >= 0 (the id's index in the on-chip set) log their distance
+__device__ __forceinline__ void dlog_append(DistLog& L, int idx, uint32_t dist_bits) {
+    const uint64_t m = __ballot(idx >= 0);
+    if (!m) return;
+    if (idx >= 0) L.log[L.n + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = ((uint64_t)dist_bits << 32) | (uint32_t)idx;
+    L.n += (uint32_t)__popcll(m);
+}
+// End of the descent: ids of the set -> out_pid (all entries, empty ones included: nothing to clear beforehand);
+// then the set's LDS is reused to sort the logged distances by index, and that array goes out in one coalesced
+// pass too (entries of empty slots are never read).  HBM sees full-sector streaming writes only.  The on-chip set
+// is destroyed: the caller clears it (visited_clear) before the next descent.
+__device__ __forceinline__ void dlog_publish(const DistLog& L, const Visited& v, uint32_t* out_pid, uint32_t* out_dist) {
+    const int lane = lane_id();
+    wave_sync();
+    uint4* t = reinterpret_cast<uint4*>(v.tab);
+    uint4* o = reinterpret_cast<uint4*>(out_pid);
+    for (uint32_t i = lane; i <= v.tmask; i += 64) o[i] = t[i];
+    visited_drain();                                       // the log's own stores have landed before it is read back
+    wave_sync();
+    constexpr int kDeep = 16;                              // log entries per lane in flight: one round trip per 1024 entries
+    for (uint32_t base = 0; base < L.n; base += 64u * kDeep) {
+        uint64_t e[kDeep];
+#pragma unroll
+        for (int u = 0; u < kDeep; u++) {
+            const uint32_t i = base + 64u * (uint32_t)u + (uint32_t)lane;
+            e[u] = L.log[i < L.n ? i : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < kDeep; u++)
+            if (base + 64u * (uint32_t)u + (uint32_t)lane < L.n) v.tab[(uint32_t)e[u]] = (uint32_t)(e[u] >> 32);
+    }
+    wave_sync();
+    o = reinterpret_cast<uint4*>(out_dist);
+    for (uint32_t i = lane; i <= v.tmask; i += 64) o[i] = t[i];
+}
+// step B: d(new, pid) from the published set of `new`'s descent, kDlogMiss if it is not there
+__device__ __forceinline__ uint32_t dlog_find(const uint32_t* P, const uint32_t* D, uint32_t bmask, uint32_t bshift, uint32_t pid) {
+    uint32_t b = (pid * 0x9E3779B1u) >> bshift;
+    for (uint32_t probe = 0; probe <= bmask; probe++) {
+        const uint4 e = *reinterpret_cast<const uint4*>(P + 4u * b);
+        if (e.x == pid) return D[4u * b];
+        if (e.y == pid) return D[4u * b + 1u];
+        if (e.z == pid) return D[4u * b + 2u];
+        if (e.w == pid) return D[4u * b + 3u];
+        if (e.w == kInvalid) return kDlogMiss;
+        b = (b + 1u) & bmask;
+    }
+    return kDlogMiss;
+}
+
 struct Counters { uint32_t n_dist, n_exp0, n_expU; };
 
 // Search::push for the very first entry point (core/lib.rs:364, :444)
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, WState& st, Visited& vis,
-                                           uint32_t* act_pid, uint32_t* act_dist, Counters& ctr, uint64_t* dlog = nullptr) {
+                                           uint32_t* act_pid, uint32_t* act_dist, Counters& ctr, DistLog& dlog) {
     const int lane = lane_id();
     visited_begin(vis);
     if (lane == 0) { act_pid[0] = 0u; visited_mark(vis, 0u); }
@@ -657,10 +707,8 @@ __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, 
     wave_sync();
     dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, 1);
     wave_sync();
-    if (lane == 0) {
-        st.W[0] = ((uint64_t)act_dist[0] << 32);  // pid 0
-        if (dlog) dlog_insert(dlog, (uint64_t)act_dist[0] << 32);
-    }
+    if (lane == 0) st.W[0] = ((uint64_t)act_dist[0] << 32);  // pid 0
+    if (dlog.log) dlog_append(dlog, lane == 0 && vis.tab ? tab_index(vis, 0u) : -1, act_dist[0]);
     wave_sync();
     st.plen = 1;
     st.cursor = 0;
@@ -772,7 +820,7 @@ __device__ __forceinline__ void w_push_keys(WState& st, uint64_t key, bool has) 
 template <int NB, int RS, int TAIL, int LAT = 0>
 __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t* rows, int row_stride, int links,
                                              const float* q, WState& st, Visited& vis, uint32_t* act_pid,
-                                             uint32_t* act_dist, Counters& ctr, bool is_zero, uint64_t* dlog = nullptr) {
+                                             uint32_t* act_dist, Counters& ctr, bool is_zero, DistLog& dlog) {
     const int lane = lane_id();
     uint32_t guard = 0;
     const bool row_lane = lane < row_stride && lane < links;
@@ -808,10 +856,11 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         if constexpr (!OVL) {
             // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
             bool fresh = false;
+            int tab_idx = -1;
             visited_begin(vis);
             if (is_nb) {
                 if (nb_pid >= ix.n) st.status |= kStBadRow;
-                else fresh = visited_insert(vis, nb_pid);
+                else fresh = visited_insert(vis, nb_pid, tab_idx);
             }
             const uint64_t fm = __ballot(fresh);
             const int na = __popcll(fm);
@@ -826,7 +875,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 ctr.n_dist += (uint32_t)na;
                 uint64_t key = kMaxKey;
                 if (fresh) key = ((uint64_t)act_dist[my] << 32) | nb_pid;
-                if (dlog && fresh) dlog_insert(dlog, key);
+                if (dlog.log) dlog_append(dlog, fresh ? tab_idx : -1, (uint32_t)(key >> 32));
                 w_push_keys(st, key, fresh);
             }
         } else {
@@ -868,7 +917,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 ctr.n_dist += (uint32_t)na;
                 uint64_t key = kMaxKey;
                 if (fresh) key = ((uint64_t)my_d << 32) | nb_pid;
-                if (dlog && fresh) dlog_insert(dlog, key);
+                if (dlog.log) dlog_append(dlog, fresh && vis.tab ? tab_index(vis, nb_pid) : -1, my_d);
                 w_push_keys(st, key, fresh);
             }
         }

@@ -87,7 +87,6 @@ __global__ __launch_bounds__(64) void validate_rows_kernel(const uint32_t* __res
 // ---------------------------------------------------------------------------
 struct Smem {
     float* q;            // stride floats
-    float* cq;           // stride floats (build only)
     uint64_t* W;         // wcap
     uint64_t* aux;       // 3*64+1 u64 (build only): news / sel / disc
     uint32_t* act_pid;   // 64
@@ -98,7 +97,7 @@ struct Smem {
 __host__ __device__ inline size_t smem_bytes(uint32_t stride, uint32_t wcap, bool build, uint32_t bloom_words = kBloomWords,
                                              uint32_t dirty_words = 0) {
     wcap = (wcap + 1u) & ~1u;   // keeps everything behind W 16-B aligned
-    size_t b = (size_t)stride * 4 * (build ? 2 : 1) + (size_t)wcap * 8 + 2 * 64 * 4 + (size_t)(bloom_words + dirty_words) * 4;
+    size_t b = (size_t)stride * 4 + (size_t)wcap * 8 + 2 * 64 * 4 + (size_t)(bloom_words + dirty_words) * 4;
     if (build) b += (size_t)(3 * 64 + 8) * 8;
     return b;
 }
@@ -106,8 +105,6 @@ __device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t w
     Smem s;
     s.q = reinterpret_cast<float*>(base);
     base += (size_t)stride * 4;
-    s.cq = reinterpret_cast<float*>(base);
-    if (build) base += (size_t)stride * 4;
     s.W = reinterpret_cast<uint64_t*>(base);
     base += (size_t)((wcap + 1u) & ~1u) * 8;
     s.aux = reinterpret_cast<uint64_t*>(base);
@@ -180,17 +177,18 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void search_kernel(IndexV
 
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
         Counters ctr{0, 0, 0};
+        DistLog nolog{nullptr, 0u};
         // search.reset(), :357: the visited set was emptied when the slot's previous search ended
-        push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr);  // :364
+        push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, nolog);  // :364
         for (int cur = (int)ix.n_upper;; cur--) {                      // :365
             const bool is_zero = cur == 0;
             st.ef = is_zero ? (int)a.ef : 1;                           // :366-371
             if (is_zero) {
-                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true);
+                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true, nolog);
                 break;
             }
             const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false);
+            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false, nolog);
             w_cull(st);                                                // :377-379
             visited_clear(vis);
             visited_begin(vis, (uint32_t)st.plen);
@@ -339,7 +337,12 @@ struct BuildArgs {
     uint32_t* row_nsel;         // [n] how many leading entries of a zero row were SELECTED (the rest is back-fill)
     uint32_t* slow;             // nodes whose update needs the full re-selection (step B2)
     uint32_t* n_slow;
-    uint64_t* dlog;             // [max_batch][kDlogCap] distances computed by each new point's descent
+    // distance log of every new point's descent (DistLog): append log, then the published set ids / distances
+    uint64_t* dlog_log;         // [max_batch][1 << tab_log2]
+    uint32_t* dlog_pid;         // [max_batch][1 << tab_log2]
+    uint32_t* dlog_dist;        // [max_batch][1 << tab_log2]
+    uint32_t tab_log2;          // log2(ids) of the descent's on-chip visited set
+    uint32_t use_dlog;          // 0: nothing is logged, step B computes every distance it needs (IDIST_BUILD_NO_DLOG, test / A-B knob)
     uint64_t* wbuf;             // [max_batch][efc] Search.nearest of every new point (step A -> step A2)
     uint32_t* wcount;           // [max_batch]
     uint32_t rt;                // step B2: selected rows kept in the LDS tile
@@ -388,8 +391,8 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
     uint64_t* sel = sm.aux + 64 + 8;
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
-    Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words,
-                a.use_bloom ? sm.bloom : nullptr, walk_mode(LAT) == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
+    Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words, nullptr, 0};
+    visited_attach_tab(vis, sm.bloom, a.tab_log2);                    // the descent always keeps its visited set on chip
     uint32_t status = 0;
     Counters tot{0, 0, 0};
     for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
@@ -408,23 +411,31 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
         wave_sync();
 
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
-        uint64_t* dlog = a.dlog + (size_t)item * kDlogCap;
+        // only the heuristic's re-selections look distances up
+        DistLog dl{a.has_heuristic && a.use_dlog ? a.dlog_log + ((size_t)item << a.tab_log2) : nullptr, 0u};
         // search.reset(), :443: the visited set was emptied when the slot's previous descent ended
-        push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, dlog);  // :444
+        push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, dl);  // :444
         const int num = a.layer == 0 ? kM2 : kM;                      // :445
         for (int cur = (int)a.top;; cur--) {                          // :447
             st.ef = cur <= (int)a.layer ? (int)a.efc : 1;             // :448-452
             if (cur > (int)a.layer) {                                 // :453-457
                 const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-                search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dlog);
+                search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dl);
                 w_cull(st);
                 visited_clear(vis);
                 visited_begin(vis, (uint32_t)st.plen);
                 for (int i = lane; i < st.plen; i += 64) visited_mark(vis, (uint32_t)st.W[i]);
                 visited_added(vis, (uint32_t)st.plen);
                 wave_sync();
+                dl.n = 0;                                             // the set was emptied: its indices start over
+                if (dl.log)
+                    for (int i0 = 0; i0 < st.plen; i0 += 64) {
+                        const bool on = i0 + lane < st.plen;
+                        const uint64_t k = on ? st.W[i0 + lane] & kKeyMask : 0ull;
+                        dlog_append(dl, on ? tab_index(vis, (uint32_t)k) : -1, (uint32_t)(k >> 32));
+                    }
             } else {                                                  // :458-461
-                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dlog);
+                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dl);
                 break;
             }
         }
@@ -433,6 +444,7 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
             // select_heuristic (:470-472) runs in step A2 with the selected rows on chip; hand Search.nearest over
             for (int i = lane; i < nw; i += 64) a.wbuf[(size_t)item * a.efc + i] = st.W[i] & kKeyMask;
             if (lane == 0) a.wcount[item] = (uint32_t)nw;
+            if (dl.log) dlog_publish(dl, vis, a.dlog_pid + ((size_t)item << a.tab_log2), a.dlog_dist + ((size_t)item << a.tab_log2));
         } else {                                                      // select_simple, :466-469, :758-760
             const int nsel = nw < kM2 ? nw : kM2;
             if (lane < nsel) sel[lane] = st.W[lane] & kKeyMask;
@@ -688,9 +700,11 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             const uint32_t new_pid = (uint32_t)knew, cd_new = (uint32_t)(knew >> 32);
             const bool selL = lane < ns0, discL = lane >= ns0 && lane < ncur;
             const uint64_t below = (1ull << lane) - 1ull;
-            const uint64_t* T = a.dlog + (size_t)(new_pid - a.start) * kDlogCap;
+            const uint32_t* TP = a.dlog_pid + ((size_t)(new_pid - a.start) << a.tab_log2);
+            const uint32_t* TD = a.dlog_dist + ((size_t)(new_pid - a.start) << a.tab_log2);
+            const uint32_t bmask = (1u << (a.tab_log2 - 2u)) - 1u, bshift = 32u - (a.tab_log2 - 2u);
             uint32_t dn = kDlogMiss;                         // d(new, selected entry of this lane)
-            if (selL) dn = dlog_find(T, cur);
+            if (selL && a.use_dlog) dn = dlog_find(TP, TD, bmask, bshift, cur);
             const bool miss = selL && dn == kDlogMiss;
             const uint64_t mm = __ballot(miss);
             if (mm) {
@@ -785,9 +799,11 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             const int nx = ns0 + k_new;
             for (int ai = 0; ai < k_new; ai++) {
                 const uint32_t a_pid = (uint32_t)news[ai];
-                const uint64_t* T = a.dlog + (size_t)(a_pid - a.start) * kDlogCap;
+                const uint32_t* TP = a.dlog_pid + ((size_t)(a_pid - a.start) << a.tab_log2);
+                const uint32_t* TD = a.dlog_dist + ((size_t)(a_pid - a.start) << a.tab_log2);
+                const uint32_t bmask = (1u << (a.tab_log2 - 2u)) - 1u, bshift = 32u - (a.tab_log2 - 2u);
                 uint32_t dv = kDlogMiss;
-                if (lane < ns0) dv = dlog_find(T, X[lane]);
+                if (lane < ns0 && a.use_dlog) dv = dlog_find(TP, TD, bmask, bshift, X[lane]);
                 if (lane < ns0) Dn[ai * kFastX + lane] = dv;
                 int nmiss = 0;
                 // columns [0, ns0) that missed + the other new points: gather those rows
