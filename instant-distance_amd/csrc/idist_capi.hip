@@ -173,10 +173,13 @@ struct Knobs {
     uint32_t tab_log2 = 0;        // IDIST_TAB_LOG2=<5..13>: size of the on-chip visited set (test knob: small sets exercise the overflow path)
     bool vis_bitmap = false;      // IDIST_VISITED=bitmap: search with bitmap + Bloom filter (16 waves per CU) instead of the on-chip set
     int tune = -1;                // IDIST_TUNE=<i> (tuning builds only, -DIDIST_TUNE): i-th experimental walk variant
+    uint32_t quad_nq = 0xFFFFFFFFu;   // IDIST_QUAD_NQ: batches up to this many queries run four waves per query (default: one
+                                      // workgroup per CU, i.e. the CU count; 0 = never)
     static Knobs from_env() {
         Knobs k;
         if (const char* e = getenv("IDIST_TUNE")) k.tune = atoi(e);
         if (const char* e = getenv("IDIST_LATENCY_NQ")) k.latency_nq = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char* e = getenv("IDIST_QUAD_NQ")) k.quad_nq = (uint32_t)std::min<unsigned long>(strtoul(e, nullptr, 10), 0xFFFFFFFEul);
         if (const char* e = getenv("IDIST_WALK")) k.classic = e[0] == 'c';
         if (const char* e = getenv("IDIST_BLOOM")) k.bloom = e[0] != '0';
         if (const char* e = getenv("IDIST_VISITED")) k.vis_bitmap = e[0] == 'b';
@@ -495,6 +498,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         const uint32_t end = cum[layer];
         uint32_t g = (uint32_t)layer == top ? 1u : std::max(cum[layer + 1], 1u);   // ranges, :275-281
         a.layer = (uint32_t)layer;
+        bool first_of_layer = true;
         while (g < end) {
             // top layer is sequential in the reference (:313-314); below, at most `cap` inserts run
             // concurrently (:316-318) and never more than 1/32 of the graph they search.
@@ -509,8 +513,11 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
             IndexView viewA = view, viewS = view;
             BuildArgs aA = a;
             if (pipe) {
-                // a sequential (B = 1) step reads the previous step's state, a concurrent one the state before that
-                const int lag = B > 1 ? 2 : 1;
+                // a sequential (B = 1) step reads the previous step's state, a concurrent one the state before that.
+                // The first step of a layer reads the previous step's state too: the snapshot of the layer above was
+                // taken from it (s1 has waited for it already), and a descent that enters the zero layer through a
+                // node of that last step must find its row, not the all-INVALID one of the older copy.
+                const int lag = B > 1 && !first_of_layer ? 2 : 1;
                 if (k > (uint64_t)lag) BCHK(hipStreamWaitEvent(s1, evS[(k - lag) & 1u], 0));
                 viewA.zero = zbuf[(k - lag) & 1u];
                 viewS.zero = zbuf[par];
@@ -563,6 +570,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
             prev_count = B;
             g += B;
             n_batches++;
+            first_of_layer = false;
             if (prog) IDIST_LAUNCH(progress_kernel, 1, 1, 0, sS, prog->slot, (unsigned long long)g, (unsigned long long)layer + 1ull);
             if (pipe) BCHK(hipEventRecord(evS[par], s2));
             if ((n_batches & 1023u) == 0) BCHK(hipGetLastError());
@@ -700,7 +708,11 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     if (tab_log2 && ctx->knobs.tab_log2) tab_log2 = std::min(tab_log2, ctx->knobs.tab_log2);
     const bool on_chip = tab_log2 != 0;
     a.tab_log2 = tab_log2;
-    const uint32_t resident = (uint32_t)ix->n_cu * (on_chip ? 4u : 16u);
+    // Narrow batches (the reference's call pattern is ONE query per Hnsw::search): a four-wave workgroup per query,
+    // one workgroup per CU — the rows of an expansion are fetched by all four SIMDs in one round trip.
+    const uint32_t quad_nq = ctx->knobs.quad_nq == 0xFFFFFFFFu ? (uint32_t)ix->n_cu : ctx->knobs.quad_nq;
+    const bool quad = on_chip && !ctx->knobs.classic && nq <= quad_nq;
+    const uint32_t resident = (uint32_t)ix->n_cu * (quad ? 1u : (on_chip ? 4u : 16u));
     CHK(ensure_slots(ctx, std::min(nq, resident), stream));
     ctx->last_ef = ef;
     a.out_pid = d_pid;
@@ -725,7 +737,10 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
 #define LAUNCH_SEARCH(NB_, RS_, TAIL_)                                                             \
     {                                                                                              \
-        if (on_chip && classic) {                                                                  \
+        if (quad) {                                                                                \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, true)>; \
+            IDIST_LAUNCH(kS, grid, 256, smem, stream, view, a);                                    \
+        } else if (on_chip && classic) {                                                           \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>;  \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } else if (on_chip) {                                                                      \

@@ -69,7 +69,21 @@ __host__ __device__ inline uint32_t blocked_pos(uint32_t e, uint32_t nb) {
 __device__ __forceinline__ float4 ldg_row4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }  // single-wave workgroup
+// Wave-level sync: the lanes of ONE wavefront hand data to each other through LDS.  A wave's LDS instructions execute
+// in issue order, so all the hardware needs is that the compiler keeps that order: a wavefront-scope fence, no
+// s_barrier and no forced s_waitcnt.  (Single-wave workgroups used __syncthreads() here; the four-wave kernel of the
+// narrow-batch walk needs its leader wave to run the same routines alone, so this must not be a workgroup barrier.)
+__device__ __forceinline__ void wave_sync() {
+#ifdef IDIST_EMU
+    ::emu::wave_sync();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+// Workgroup barrier of the multi-wave kernels (s_barrier + LDS fence)
+__device__ __forceinline__ void block_sync() { __syncthreads(); }
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 __device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
     uint32_t lo = bcast_u32((uint32_t)v, src), hi = bcast_u32((uint32_t)(v >> 32), src);
@@ -129,9 +143,11 @@ __device__ __forceinline__ float fold_chains(float acc, bool has_tail, float tq,
 // one HBM round trip per 8*RIF rows instead of one per 8 rows, and the query fragment of the lane sits in
 // registers (there is one wave per SIMD in this mode, so nothing else would hide the LDS reads).  Same
 // arithmetic, same results.
-template <int NB, int RS, int TAIL, int RIF, bool QREGS = true>
+// RSTEP / first: rows between the rounds a wave keeps in flight and its first row.  The default (8, 0) walks the list
+// front to back; the four-wave walk gives wave w the rounds w and w + 4 of at most 8 (RSTEP = 32, first = 8 w).
+template <int NB, int RS, int TAIL, int RIF, bool QREGS = true, int RSTEP = 8>
 __device__ __forceinline__ void dist_rounds_inflight(const IndexView& ix, const VecView qv, const uint32_t* act_pid,
-                                                     uint32_t* act_dist, int na) {
+                                                     uint32_t* act_dist, int na, int first = 0) {
     static_assert(NB >= 0 && RS >= 0 && TAIL >= 0 && RIF >= 1, "compile-time layout only");
     const int lane = lane_id();
     const int g = lane >> 3, j = lane & 7;
@@ -146,12 +162,12 @@ __device__ __forceinline__ void dist_rounds_inflight(const IndexView& ix, const 
 #pragma unroll
     for (int c = 0; c < RS; c++) qr[c] = qv.rem[c * 8 + j];
     const float qt = TAIL ? qv.rem[RS * 8 + (j & 3)] : 0.0f;
-    for (int base = 0; base < na; base += 8 * RIF) {
+    for (int base = first; base < na; base += RSTEP * RIF) {
         float4 p[RIF][NBA];
         float pr[RIF][RSA], pt[RIF];
 #pragma unroll
         for (int r = 0; r < RIF; r++) {
-            const int k = base + 8 * r + g;
+            const int k = base + RSTEP * r + g;
             pt[r] = 0.0f;
             if (k < na) {
                 const float* row = ix.points + (size_t)act_pid[k] * ix.stride;
@@ -166,7 +182,7 @@ __device__ __forceinline__ void dist_rounds_inflight(const IndexView& ix, const 
 #pragma unroll
         for (int r = 0; r < RIF; r++) {
             acc[r] = 0.0f;
-            if (base + 8 * r + g < na) {
+            if (base + RSTEP * r + g < na) {
 #pragma unroll
                 for (int u = 0; u < NB; u++) {
                     float4 w;
@@ -187,7 +203,7 @@ __device__ __forceinline__ void dist_rounds_inflight(const IndexView& ix, const 
         }
 #pragma unroll
         for (int r = 0; r < RIF; r++) {
-            const int k = base + 8 * r + g;
+            const int k = base + RSTEP * r + g;
             const bool on = k < na;
             const float res = fold_chains(acc[r], TAIL && on, qt, pt[r]);
             if (on && j == 0) act_dist[k] = canon_bits(res, ix.metric);
@@ -200,13 +216,13 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q,
                                             uint32_t* act_dist, int na);
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void dist_rounds(const IndexView& ix, const VecView qv, const uint32_t* act_pid,
-                                            uint32_t* act_dist, int na) {
+                                            uint32_t* act_dist, int na, int first = 0, int step = 8) {
     const int lane = lane_id();
     const int g = lane >> 3, j = lane & 7;
     const int nb = NB >= 0 ? NB : (int)ix.nb;
     const int rs = RS >= 0 ? RS : (int)ix.rs;
     const int tail = TAIL >= 0 ? TAIL : (int)ix.tail;
-    for (int base = 0; base < na; base += 8) {
+    for (int base = first; base < na; base += step) {
         const int k = base + g;
         const bool on = k < na;
         const uint32_t pid = on ? act_pid[k] : 0u;
@@ -264,6 +280,15 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q,
     dist_rounds<NB, RS, TAIL>(ix, natural_view(q, NB >= 0 ? NB : (int)ix.nb), act_pid, act_dist, na);
 }
 
+// Four-wave walk: the share of wave `wv` of one expansion's distance pass — rounds wv and wv + 4 of the (at most 8)
+// rounds of 8 rows, both in flight at once.  Same arithmetic per row as every other variant.
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ void dist_rounds_quad(const IndexView& ix, const float* q, const uint32_t* act_pid,
+                                                 uint32_t* act_dist, int na, int wv) {
+    if constexpr (NB >= 0) dist_rounds_inflight<NB, RS, TAIL, 2, true, 32>(ix, natural_view(q, NB), act_pid, act_dist, na, 8 * wv);
+    else dist_rounds<NB, RS, TAIL>(ix, natural_view(q, (int)ix.nb), act_pid, act_dist, na, 8 * wv, 32);
+}
+
 // Walk modes of the graph kernels (search_layer):
 //   kWalkClassic  one distance round in flight, query tile in LDS: smallest register footprint
 //   kWalkLatency  narrow batches: few waves per CU, so each wave overlaps as much as its registers allow
@@ -275,10 +300,12 @@ enum : int { kWalkClassic = 0, kWalkLatency = 1, kWalkOverlap = 2 };
 //   bits 0-1 mode, bits 4-7 rounds in flight (0 = the mode's default), bit 8 query fragment read from LDS
 //   instead of registers, bits 12-14 waves per SIMD the kernel is compiled for (0 = compiler's choice)
 //   bit 9 visited set kept on chip (LDS hash set, HBM bitmap only as overflow) instead of bitmap + Bloom filter
-constexpr int walk_code(int mode, int rif = 0, bool q_lds = false, int waves = 0, bool vis_lds = false) {
-    return mode | (rif << 4) | ((q_lds ? 1 : 0) << 8) | ((vis_lds ? 1 : 0) << 9) | (waves << 12);
+//   bit 10 four-wave workgroup per walk: wave 0 leads (this routine), all four share each distance pass (QuadCtl)
+constexpr int walk_code(int mode, int rif = 0, bool q_lds = false, int waves = 0, bool vis_lds = false, bool quad = false) {
+    return mode | (rif << 4) | ((q_lds ? 1 : 0) << 8) | ((vis_lds ? 1 : 0) << 9) | ((quad ? 1 : 0) << 10) | (waves << 12);
 }
 constexpr bool walk_vis_lds(int code) { return ((code >> 9) & 1) != 0; }
+constexpr bool walk_quad(int code) { return ((code >> 10) & 1) != 0; }
 constexpr int walk_mode(int code) { return code & 3; }
 constexpr int walk_rif(int code) { return (code >> 4) & 15; }
 constexpr bool walk_q_lds(int code) { return ((code >> 8) & 1) != 0; }
@@ -696,6 +723,49 @@ __device__ __forceinline__ uint32_t dlog_find(const uint32_t* P, const uint32_t*
 
 struct Counters { uint32_t n_dist, n_exp0, n_expU; };
 
+// ---------------------------------------------------------------------------
+// Four waves per walk (narrow batches: Hnsw::search is one query per call, core/lib.rs:352-356).  A single wave
+// walking the graph waits for two or three dependent HBM round trips per expansion and runs the FMA chains of ~50
+// rows on one SIMD.  Here a workgroup of four waves — one per SIMD of a CU — owns the query: wave 0 (the leader)
+// runs the walk exactly as the single-wave kernels do (pop, adjacency row, visited set, pushes in slot order), but
+// every distance pass is shared: round r of 8 rows goes to wave r & 3, so the up to 64 rows of an expansion are
+// requested at once and cost ONE round trip and a quarter of the arithmetic per SIMD.  Protocol, two workgroup
+// barriers per expansion:
+//     leader: act_pid[0..na) and ctl->na written | B1 | its share of the pass | B2 | reads act_dist, pushes, ...
+//     helper:                         (waits)     | B1 | its share of the pass | B2 | (waits at the next B1)
+// ctl->na = kQuadExit releases the helpers when the leader's work queue is empty.  Decisions, their order and the
+// arithmetic per row are those of the other variants: results are bit-identical.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kQuadExit = 0xFFFFFFFFu;
+struct QuadCtl { uint32_t na; uint32_t pad[3]; };
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ void quad_dist_pass(const IndexView& ix, const float* q, QuadCtl* ctl, const uint32_t* act_pid,
+                                               uint32_t* act_dist, int na) {
+    if (na <= 8) {                                                     // a single round: not worth two barriers
+        dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0);
+        return;
+    }
+    if (lane_id() == 0) ctl->na = (uint32_t)na;
+    block_sync();                                                      // B1
+    dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0);
+    block_sync();                                                      // B2
+}
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const float* q, const QuadCtl* ctl, const uint32_t* act_pid,
+                                                 uint32_t* act_dist, int wv) {
+    for (;;) {
+        block_sync();                                                  // B1
+        const uint32_t na = uniform_u32(ctl->na);
+        if (na == kQuadExit) break;
+        dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, (int)na, wv);
+        block_sync();                                                  // B2
+    }
+}
+__device__ __forceinline__ void quad_release_helpers(QuadCtl* ctl) {
+    if (lane_id() == 0) ctl->na = kQuadExit;
+    block_sync();                                                      // B1 of the helpers' last iteration
+}
+
 // Search::push for the very first entry point (core/lib.rs:364, :444)
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, WState& st, Visited& vis,
@@ -820,7 +890,8 @@ __device__ __forceinline__ void w_push_keys(WState& st, uint64_t key, bool has) 
 template <int NB, int RS, int TAIL, int LAT = 0>
 __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t* rows, int row_stride, int links,
                                              const float* q, WState& st, Visited& vis, uint32_t* act_pid,
-                                             uint32_t* act_dist, Counters& ctr, bool is_zero, DistLog& dlog) {
+                                             uint32_t* act_dist, Counters& ctr, bool is_zero, DistLog& dlog,
+                                             QuadCtl* quad = nullptr) {
     const int lane = lane_id();
     uint32_t guard = 0;
     const bool row_lane = lane < row_stride && lane < links;
@@ -870,7 +941,8 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 const int my = __popcll(fm & ((1ull << lane) - 1ull));
                 if (fresh) act_pid[my] = nb_pid;                                        // keeps slot order
                 wave_sync();
-                dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na);     // :709-710
+                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, na);
+                else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na);     // :709-710
                 wave_sync();
                 ctr.n_dist += (uint32_t)na;
                 uint64_t key = kMaxKey;

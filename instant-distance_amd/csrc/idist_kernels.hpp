@@ -91,13 +91,14 @@ struct Smem {
     uint64_t* aux;       // 3*64+1 u64 (build only): news / sel / disc
     uint32_t* act_pid;   // 64
     uint32_t* act_dist;  // 64
+    QuadCtl* ctl;        // hand-over word of the four-wave walk (16 B)
     uint32_t* dirty;     // dirty-block bitmap of the visited set (graph walks only), dirty_words dwords
     uint32_t* bloom;     // kBloomWords / kBloomLatWords, last in the carve-up (graph walks only)
 };
 __host__ __device__ inline size_t smem_bytes(uint32_t stride, uint32_t wcap, bool build, uint32_t bloom_words = kBloomWords,
                                              uint32_t dirty_words = 0) {
     wcap = (wcap + 1u) & ~1u;   // keeps everything behind W 16-B aligned
-    size_t b = (size_t)stride * 4 + (size_t)wcap * 8 + 2 * 64 * 4 + (size_t)(bloom_words + dirty_words) * 4;
+    size_t b = (size_t)stride * 4 + (size_t)wcap * 8 + 2 * 64 * 4 + sizeof(QuadCtl) + (size_t)(bloom_words + dirty_words) * 4;
     if (build) b += (size_t)(3 * 64 + 8) * 8;
     return b;
 }
@@ -111,7 +112,8 @@ __device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t w
     if (build) base += (size_t)(3 * 64 + 8) * 8;
     s.act_pid = reinterpret_cast<uint32_t*>(base);
     s.act_dist = s.act_pid + 64;
-    s.dirty = s.act_dist + 64;
+    s.ctl = reinterpret_cast<QuadCtl*>(s.act_dist + 64);
+    s.dirty = s.act_dist + 64 + sizeof(QuadCtl) / 4;
     s.bloom = s.dirty + dirty_words;
     return s;
 }
@@ -149,12 +151,21 @@ __device__ __forceinline__ void visited_attach_tab(Visited& v, uint32_t* mem, ui
 #define IDIST_WAVES_ATTR(LAT_) \
     __attribute__((amdgpu_waves_per_eu(walk_waves(LAT_) ? walk_waves(LAT_) : 1, walk_waves(LAT_) ? walk_waves(LAT_) : 8)))
 #endif
+// Walk codes with the quad bit run four-wave workgroups (256 threads): wave 0 is the walk below, waves 1-3 only
+// take their share of every distance pass (QuadCtl, idist_device.hpp).
 template <int NB, int RS, int TAIL, int LAT = 0>
-__global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void search_kernel(IndexView ix, SearchArgs a) {
+__global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) void search_kernel(IndexView ix, SearchArgs a) {
     IDIST_DYN_SMEM(smem_raw);
     const Smem sm = carve(smem_raw, ix.stride, a.wcap, false, a.vis.dirty_words);
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
+    if constexpr (walk_quad(LAT)) {
+        const int wv = (int)uniform_u32(threadIdx.x >> 6);
+        if (wv != 0) {
+            quad_helper_loop<NB, RS, TAIL>(ix, sm.q, sm.ctl, sm.act_pid, sm.act_dist, wv);
+            return;
+        }
+    }
     Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words,
                 a.use_bloom ? sm.bloom : nullptr, walk_mode(LAT) == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
     if constexpr (walk_vis_lds(LAT)) visited_attach_tab(vis, sm.bloom, a.tab_log2);
@@ -184,11 +195,11 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void search_kernel(IndexV
             const bool is_zero = cur == 0;
             st.ef = is_zero ? (int)a.ef : 1;                           // :366-371
             if (is_zero) {
-                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true, nolog);
+                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true, nolog, sm.ctl);
                 break;
             }
             const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false, nolog);
+            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false, nolog, sm.ctl);
             w_cull(st);                                                // :377-379
             visited_clear(vis);
             visited_begin(vis, (uint32_t)st.plen);
@@ -219,6 +230,7 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void search_kernel(IndexV
         status |= st.status;
         visited_clear(vis);                                            // leave the slot empty for its next search
     }
+    if constexpr (walk_quad(LAT)) quad_release_helpers(sm.ctl);
     if (lane == 0 && status) atomicOr(a.status, status);
 }
 

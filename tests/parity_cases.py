@@ -14,20 +14,29 @@ INVALID = 0xFFFFFFFF
 # Variants of the graph walk (idist_device.hpp): the default keeps the visited set on chip (LDS hash set, HBM bitmap
 # as overflow — forced early with a tiny set); IDIST_VISITED=bitmap selects the bitmap + Bloom-filter walks (classic /
 # latency / overlap by batch width and IDIST_WALK).  All must give the reference's results.
-SEARCH_VARIANTS = (("on-chip", {}),
+SEARCH_VARIANTS = (("default (narrow batches: four waves per query)", {}),
+                   ("on-chip", {"IDIST_QUAD_NQ": "0"}),
+                   ("four waves per query", {"IDIST_QUAD_NQ": "4000000000"}),
+                   ("four waves per query, set of 128 ids then bitmap", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_LOG2": "7"}),
                    ("on-chip classic", {"IDIST_WALK": "classic"}),
-                   ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7"}),
+                   ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7", "IDIST_QUAD_NQ": "0"}),
                    ("on-chip, set of 32 ids: bitmap from the start", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}),
                    ("bitmap overlap", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "0"}),
                    ("bitmap latency", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "4000000000"}),
                    ("bitmap classic", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "0", "IDIST_WALK": "classic"}))
+# The descent of an insertion shares the walk code; what varies there is the walk mode (classic / overlap) and the size
+# of the on-chip visited set — it never runs four waves per item and has no bitmap-only variant.
+BUILD_VARIANTS = (("on-chip", {}),
+                  ("on-chip classic", {"IDIST_WALK": "classic"}),
+                  ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7"}),
+                  ("on-chip, set of 32 ids: bitmap from the start", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}))
 
 
 @contextlib.contextmanager
 def search_variant(env):
     if isinstance(env, str):                     # a bare IDIST_LATENCY_NQ value
         env = {"IDIST_LATENCY_NQ": env}
-    keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2")
+    keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)
@@ -135,7 +144,7 @@ def check_build_exact(ida, oracle, n, dim, metric=0, kind="uniform", ef_construc
     oix = oracle.Index.build(pts, cfg, threads=1)
     b = (ida.Builder().metric(metric).max_batch(1).ef_construction(ef_construction)
          .select_heuristic(ida.Heuristic(False, keep_pruned) if heuristic else None))
-    for _, lat in SEARCH_VARIANTS:        # the descent of an insertion has the same two variants as the search
+    for _, lat in BUILD_VARIANTS:         # the descent of an insertion has the same variants as the search
         with search_variant(lat):
             h = ida.Hnsw.from_ordered_points(pts, b)
         zero, layers = h.into_parts()

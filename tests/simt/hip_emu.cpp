@@ -65,6 +65,7 @@ static void init_lane(Lane& l, uint32_t tid) {
 static const char* op_name(int op) {
     switch (op) {
         case OP_SYNC: return "__syncthreads";
+        case OP_WSYNC: return "wave_sync";
         case OP_BALLOT: return "__ballot";
         case OP_SHFL: return "__shfl";
         case OP_SHFL_XOR: return "__shfl_xor";

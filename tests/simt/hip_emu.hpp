@@ -37,7 +37,7 @@ namespace emu {
 
 struct Dim3 { uint32_t x, y, z; };
 
-enum Op { OP_NONE = 0, OP_SYNC, OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_READFIRST, OP_MFMA_32x32x2, OP_DPP };
+enum Op { OP_NONE = 0, OP_SYNC, OP_WSYNC, OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_READFIRST, OP_MFMA_32x32x2, OP_DPP };
 
 struct Lane {
     void* sp = nullptr;          // saved stack pointer
@@ -82,6 +82,10 @@ inline uint64_t collective(int op, uint64_t v, int arg) {
 }
 
 void launch(uint32_t grid, uint32_t block, size_t smem_bytes, const std::function<void()>& body);
+
+// wave-level sync of the kernels (idist::wave_sync): a rendezvous of the 64 lanes of ONE wave — on hardware the
+// lanes of a wave run in lockstep and their LDS accesses execute in order; here every lane is a fiber
+inline void wave_sync() { collective(OP_WSYNC, 0, 0); }
 
 }  // namespace emu
 
