@@ -721,7 +721,18 @@ __device__ __forceinline__ uint32_t dlog_find(const uint32_t* P, const uint32_t*
     return kDlogMiss;
 }
 
-struct Counters { uint32_t n_dist, n_exp0, n_expU; };
+struct Counters {
+    uint32_t n_dist, n_exp0, n_expU;
+#ifdef IDIST_PHASES
+    // instrumented build (make phases): 10-ns ticks of one walk spent before / in / after the distance passes
+    uint32_t t_pre = 0, t_dist = 0, t_post = 0;
+#endif
+};
+#ifdef IDIST_PHASES
+#define IDIST_TICK() ((uint32_t)wall_clock64())
+#else
+#define IDIST_TICK() 0u
+#endif
 
 // ---------------------------------------------------------------------------
 // Four waves per walk (narrow batches: Hnsw::search is one query per call, core/lib.rs:352-356).  A single wave
@@ -900,6 +911,8 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     constexpr bool OVL = walk_mode(LAT) != kWalkClassic && !walk_vis_lds(LAT);
     uint32_t pf_pid = kInvalid, pf_row = kInvalid;
     for (;;) {
+        [[maybe_unused]] const uint32_t tk0 = IDIST_TICK();
+        [[maybe_unused]] bool tk_on = false;
         const int ci = w_pop(st);                         // :599-604
         if (ci < 0) break;
         const uint64_t c = st.W[ci];
@@ -941,9 +954,17 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 const int my = __popcll(fm & ((1ull << lane) - 1ull));
                 if (fresh) act_pid[my] = nb_pid;                                        // keeps slot order
                 wave_sync();
+                [[maybe_unused]] const uint32_t tk1 = IDIST_TICK();
                 if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, na);
                 else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na);     // :709-710
                 wave_sync();
+#ifdef IDIST_PHASES
+                const uint32_t tk2 = IDIST_TICK();
+                ctr.t_pre += tk1 - tk0;
+                ctr.t_dist += tk2 - tk1;
+                ctr.t_post -= tk2;                         // + the tick after the truncate below
+                tk_on = true;
+#endif
                 ctr.n_dist += (uint32_t)na;
                 uint64_t key = kMaxKey;
                 if (fresh) key = ((uint64_t)act_dist[my] << 32) | nb_pid;
@@ -994,6 +1015,9 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             }
         }
         w_truncate(st);                                    // :612
+#ifdef IDIST_PHASES
+        if (tk_on) ctr.t_post += IDIST_TICK();
+#endif
         if (++guard > ix.n + 64u) { st.status |= kStGuard; break; }
     }
 }
