@@ -818,77 +818,75 @@ __device__ __forceinline__ int w_peek_next(const WState& st, int after) {
 // list plus a count over the earlier accepted lanes, and the accepted keys are merged into W in one pass
 // instead of one shifted insertion each.
 constexpr int kPushChunks = 8;   // one-pass merge for W up to 512 entries, sequential insertion beyond
-__device__ __forceinline__ void w_push_keys(WState& st, uint64_t key, bool has) {
+// One pass over the candidate keys in slot order with the old list held in registers (NC chunks of 64 entries, entry
+// c * 64 + lane in w[c]); no LDS access inside the loop:
+//   r0   rank of the key in the OLD list (Vec::binary_search, :712) = number of old entries below it, counted with one
+//        ballot per chunk;
+//   cnt  per lane: accepted keys so far that are smaller than the lane's own key.  When slot j is decided it holds
+//        exactly the earlier-slot keys in front of key j; after the loop, all accepted keys in front of the lane's key;
+//   sh   per old entry: accepted keys below it (entry t lies above key j iff t >= r0_j) = how far it moves up.
+template <int NC>
+__device__ __forceinline__ void w_push_merge(WState& st, uint64_t key, uint64_t pm) {
     const int lane = lane_id();
+    const int plen = st.plen;
+    uint64_t w[NC];
+    int sh[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int t = c * 64 + lane;
+        sh[c] = 0;
+        w[c] = t < plen ? st.W[t] : ~0ull;                 // beyond the list: above every key
+    }
+    const uint32_t k_lo = (uint32_t)key, k_hi = (uint32_t)(key >> 32);
+    uint32_t cnt = 0;
+    bool acc = false;
+    int my_r0 = 0, first = plen, nacc = 0;
+    for (uint64_t m = pm; m; m &= m - 1ull) {              // slot order
+        const int j = __builtin_ctzll(m);
+        const uint64_t kj = ((uint64_t)readlane_u32(k_hi, j) << 32) | readlane_u32(k_lo, j);
+        int r0 = 0;
+#pragma unroll
+        for (int c = 0; c < NC; c++) r0 += __popcll(__ballot((w[c] & kKeyMask) < kj));
+        const int cj = (int)readlane_u32(cnt, j);
+        if (r0 + cj < st.ef) {                             // idx < ef, :713
+            cnt += kj < key ? 1u : 0u;
+#pragma unroll
+            for (int c = 0; c < NC; c++) sh[c] += c * 64 + lane >= r0 ? 1 : 0;
+            if (lane == j) { acc = true; my_r0 = r0; }
+            first = r0 < first ? r0 : first;
+            nacc++;
+        }
+    }
+    if (!nacc) return;
+    // merge: an old entry moves up by the number of accepted keys below it, an accepted key lands at its old
+    // rank plus the number of accepted keys below it
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+        if (sh[c] > 0 && c * 64 + lane < plen) st.W[c * 64 + lane + sh[c]] = w[c];
+    if (acc) st.W[my_r0 + (int)cnt] = key;
+    wave_sync();
+    st.plen = plen + nacc;
+    if (first < st.cursor) st.cursor = first;
+}
+__device__ __forceinline__ void w_push_keys(WState& st, uint64_t key, bool has) {
     // entries that cannot have rank < ef even now never will (W only improves)
     const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
     const bool cand = has && key < thr;
     uint64_t pm = __ballot(cand);
     if (!pm) return;
     const int plen = st.plen;
-    if (plen > 64 * kPushChunks) {
-        while (pm) {
-            const int i = __builtin_ctzll(pm);
-            pm &= pm - 1ull;
-            const uint64_t k = bcast_u64(key, i);
-            const int idx = w_rank(st, k);             // :712
-            if (idx < st.ef) w_insert(st, idx, k);     // :713-719
-        }
-        return;
+    if (plen <= 64) return w_push_merge<1>(st, key, pm);
+    if (plen <= 128) return w_push_merge<2>(st, key, pm);
+    if (plen <= 256) return w_push_merge<4>(st, key, pm);
+    if (plen <= 64 * kPushChunks) return w_push_merge<kPushChunks>(st, key, pm);
+    while (pm) {
+        const int i = __builtin_ctzll(pm);
+        pm &= pm - 1ull;
+        const uint64_t k = bcast_u64(key, i);
+        const int idx = w_rank(st, k);             // :712
+        if (idx < st.ef) w_insert(st, idx, k);     // :713-719
     }
-    // rank in the old list (Vec::binary_search, :712)
-    int r0 = 0;
-    if (cand) {
-        int lo = 0, hi = plen;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((st.W[mid] & kKeyMask) < key) lo = mid + 1; else hi = mid;
-        }
-        r0 = lo;
-    }
-    const uint32_t k_lo = (uint32_t)key, k_hi = (uint32_t)(key >> 32);
-    bool acc = false;
-    for (uint64_t m = pm; m; m &= m - 1ull) {              // slot order
-        const int i = __builtin_ctzll(m);
-        const uint64_t ki = ((uint64_t)readlane_u32(k_hi, i) << 32) | readlane_u32(k_lo, i);
-        const int ri = (int)readlane_u32((uint32_t)r0, i);
-        const int c = __popcll(__ballot(acc && key < ki));
-        if (lane == i) acc = ri + c < st.ef;               // idx < ef, :713
-    }
-    const uint64_t A = __ballot(acc);
-    if (!A) return;
-    // merge: an old entry moves up by the number of accepted keys below it, an accepted key lands at its old
-    // rank plus the number of accepted keys below it
-    int first = plen;
-    for (uint64_t m = A; m; m &= m - 1ull) {
-        const int ri = (int)readlane_u32((uint32_t)r0, __builtin_ctzll(m));
-        first = ri < first ? ri : first;
-    }
-    const int c0 = first >> 6;
-    uint64_t w[kPushChunks];
-    int sh[kPushChunks];
-#pragma unroll
-    for (int c = 0; c < kPushChunks; c++) {
-        const int t = c * 64 + lane;
-        sh[c] = 0;
-        w[c] = (c >= c0 && t < plen) ? st.W[t] : 0ull;     // 0 never moves (no key is below it)
-    }
-    int below = 0;
-    for (uint64_t m = A; m; m &= m - 1ull) {
-        const int i = __builtin_ctzll(m);
-        const uint64_t kj = ((uint64_t)readlane_u32(k_hi, i) << 32) | readlane_u32(k_lo, i);
-        below += (acc && kj < key) ? 1 : 0;
-#pragma unroll
-        for (int c = 0; c < kPushChunks; c++) sh[c] += (w[c] & kKeyMask) > kj ? 1 : 0;
-    }
-    wave_sync();
-#pragma unroll
-    for (int c = 0; c < kPushChunks; c++)
-        if (sh[c] > 0) st.W[c * 64 + lane + sh[c]] = w[c];
-    if (acc) st.W[r0 + below] = key;
-    wave_sync();
-    st.plen = plen + __popcll(A);
-    if (first < st.cursor) st.cursor = first;
 }
 
 // LAT = kWalkClassic: one thing at a time per wave (many waves per CU hide the latencies).
@@ -936,6 +934,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         const uint64_t inval = __ballot(nb_pid == kInvalid);
         const int nvalid = inval ? __builtin_ctzll(inval) : 64;
         const bool is_nb = lane < nvalid;
+        [[maybe_unused]] const uint32_t tkA = IDIST_TICK();       // pop, peek and the adjacency row are in
 
         if constexpr (!OVL) {
             // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
@@ -960,9 +959,15 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 wave_sync();
 #ifdef IDIST_PHASES
                 const uint32_t tk2 = IDIST_TICK();
+#if IDIST_PHASES == 2
+                ctr.t_pre += tkA - tk0;                    // pop + peek + adjacency row
+                ctr.t_dist += tk1 - tkA;                   // visited set + compaction
+                ctr.t_post -= tk2;                         // + the tick after the push below: push alone
+#else
                 ctr.t_pre += tk1 - tk0;
                 ctr.t_dist += tk2 - tk1;
                 ctr.t_post -= tk2;                         // + the tick after the truncate below
+#endif
                 tk_on = true;
 #endif
                 ctr.n_dist += (uint32_t)na;
@@ -970,6 +975,9 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 if (fresh) key = ((uint64_t)act_dist[my] << 32) | nb_pid;
                 if (dlog.log) dlog_append(dlog, fresh ? tab_idx : -1, (uint32_t)(key >> 32));
                 w_push_keys(st, key, fresh);
+#if defined(IDIST_PHASES) && IDIST_PHASES == 2
+                if (tk_on) { ctr.t_post += IDIST_TICK(); tk_on = false; }
+#endif
             }
         } else {
             bool sure = false, maybe = false;

@@ -19,9 +19,9 @@ import instant_distance_amd as ida  # noqa: E402
 from instant_distance_amd import _capi  # noqa: E402
 
 out_path = sys.argv[1]
-phases = len(sys.argv) > 2 and sys.argv[2] == "phases"
-if phases:
-    _capi._singleton = _capi.Lib(os.path.join(ROOT, "instant-distance_amd", "csrc", "libidist_phases.so"))
+phases = len(sys.argv) > 2 and sys.argv[2].startswith("phases")
+if phases:      # "phases": before / in / after the distance passes; "phases2": pop+peek+adjacency / visited set+compaction / push
+    _capi._singleton = _capi.Lib(os.path.join(ROOT, "instant-distance_amd", "csrc", "libidist_" + sys.argv[2] + ".so"))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 fo = open(out_path, "a")
 
@@ -38,7 +38,7 @@ d_pts = bench.synth(torch, n, dim, 123456789, dev)
 d_q = bench.synth(torch, nq, dim, 123456790, dev)
 torch.cuda.synchronize()
 h = ida.Hnsw.from_device_points(d_pts.data_ptr(), n, dim, ida.Builder())
-emit(what="build", seconds=h.build_stats().seconds, phases=phases)
+emit(what="build", seconds=h.build_stats().seconds, phases=sys.argv[2] if phases else None)
 q_host = d_q[:512].cpu().numpy()
 VARIANTS = (("single wave", {"IDIST_QUAD_NQ": "0"}), ("four waves", {"IDIST_QUAD_NQ": "4000000000"}))
 
@@ -84,3 +84,16 @@ for nm, env in VARIANTS:
         c = o[3][:256].cpu().numpy().astype(np.float64) * 1e-5      # 10-ns ticks -> ms
         row.update(pre_ms=round(float(c[:, 0].mean()), 4), dist_ms=round(float(c[:, 1].mean()), 4), post_ms=round(float(c[:, 2].mean()), 4))
     emit(**row)
+
+if phases:      # the same shares inside a full 10k-query batch (one wave per SIMD, the chip loaded)
+    os.environ.pop("IDIST_QUAD_NQ", None)
+    ob = (torch.empty(nq, 100, dtype=torch.int32, device=dev), torch.empty(nq, 100, dtype=torch.float32, device=dev),
+          torch.empty(nq, dtype=torch.int32, device=dev), torch.zeros(nq, 3, dtype=torch.int32, device=dev))
+    s = ida.Search()
+    for _ in range(3):
+        h.search_batch_device(s, d_q.data_ptr(), nq, ob[0].data_ptr(), ob[1].data_ptr(), ob[2].data_ptr(), ob[3].data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    c = ob[3].cpu().numpy().astype(np.float64) * 1e-5
+    emit(what="full batch, per query", kernel_ms=round(float(np.median(s.kernel_times_ms(2))), 3), a_ms=round(float(c[:, 0].mean()), 4),
+         b_ms=round(float(c[:, 1].mean()), 4), c_ms=round(float(c[:, 2].mean()), 4))
