@@ -145,9 +145,12 @@ __device__ __forceinline__ float fold_chains(float acc, bool has_tail, float tq,
 // arithmetic, same results.
 // RSTEP / first: rows between the rounds a wave keeps in flight and its first row.  The default (8, 0) walks the list
 // front to back; the four-wave walk gives wave w the rounds w and w + 4 of at most 8 (RSTEP = 32, first = 8 w).
-template <int NB, int RS, int TAIL, int RIF, bool QREGS = true, int RSTEP = 8>
+// mid(): work of the caller that does not depend on the distances — it runs once, after the first batch of row loads
+// has been issued and before anything waits for them (the walk inserts the new ids into its visited set there).
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <int NB, int RS, int TAIL, int RIF, bool QREGS = true, int RSTEP = 8, class Mid = NoMid>
 __device__ __forceinline__ void dist_rounds_inflight(const IndexView& ix, const VecView qv, const uint32_t* act_pid,
-                                                     uint32_t* act_dist, int na, int first = 0) {
+                                                     uint32_t* act_dist, int na, int first = 0, Mid mid = Mid()) {
     static_assert(NB >= 0 && RS >= 0 && TAIL >= 0 && RIF >= 1, "compile-time layout only");
     const int lane = lane_id();
     const int g = lane >> 3, j = lane & 7;
@@ -178,6 +181,7 @@ __device__ __forceinline__ void dist_rounds_inflight(const IndexView& ix, const 
                 if (TAIL) pt[r] = row[NB * 32 + RS * 8 + (j & 3)];
             }
         }
+        if (base == first) mid();
         float acc[RIF];
 #pragma unroll
         for (int r = 0; r < RIF; r++) {
@@ -282,11 +286,16 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q,
 
 // Four-wave walk: the share of wave `wv` of one expansion's distance pass — rounds wv and wv + 4 of the (at most 8)
 // rounds of 8 rows, both in flight at once.  Same arithmetic per row as every other variant.
-template <int NB, int RS, int TAIL>
+template <int NB, int RS, int TAIL, class Mid = NoMid>
 __device__ __forceinline__ void dist_rounds_quad(const IndexView& ix, const float* q, const uint32_t* act_pid,
-                                                 uint32_t* act_dist, int na, int wv) {
-    if constexpr (NB >= 0) dist_rounds_inflight<NB, RS, TAIL, 2, true, 32>(ix, natural_view(q, NB), act_pid, act_dist, na, 8 * wv);
-    else dist_rounds<NB, RS, TAIL>(ix, natural_view(q, (int)ix.nb), act_pid, act_dist, na, 8 * wv, 32);
+                                                 uint32_t* act_dist, int na, int wv, Mid mid = Mid()) {
+    if constexpr (NB >= 0) {
+        if (8 * wv >= na) mid();                               // no row for this wave: the loop body never runs
+        dist_rounds_inflight<NB, RS, TAIL, 2, true, 32>(ix, natural_view(q, NB), act_pid, act_dist, na, 8 * wv, mid);
+    } else {
+        mid();
+        dist_rounds<NB, RS, TAIL>(ix, natural_view(q, (int)ix.nb), act_pid, act_dist, na, 8 * wv, 32);
+    }
 }
 
 // Walk modes of the graph kernels (search_layer):
@@ -328,13 +337,17 @@ constexpr int rounds_in_flight() {
     if (walk_mode(WALK) == kWalkLatency) return NB <= 4 ? 8 : (NB <= 12 ? IDIST_RIF9 : (NB <= 24 ? 2 : 1));
     return NB <= 12 ? IDIST_RIF_OVERLAP : (NB <= 24 ? IDIST_RIF24_OVERLAP : 1);
 }
-template <int NB, int RS, int TAIL, int WALK>
+template <int NB, int RS, int TAIL, int WALK, class Mid = NoMid>
 __device__ __forceinline__ void dist_rounds_walk(const IndexView& ix, const float* q, const uint32_t* act_pid,
-                                                 uint32_t* act_dist, int na) {
+                                                 uint32_t* act_dist, int na, Mid mid = Mid()) {
     constexpr int RIF = rounds_in_flight<NB, WALK>();
-    if constexpr (RIF > 1 || (walk_rif(WALK) == 1 && NB >= 0))
-        dist_rounds_inflight<NB, RS, TAIL, RIF, !walk_q_lds(WALK)>(ix, natural_view(q, NB), act_pid, act_dist, na);
-    else dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);
+    if constexpr (RIF > 1 || (walk_rif(WALK) == 1 && NB >= 0)) {
+        if (na <= 0) mid();
+        dist_rounds_inflight<NB, RS, TAIL, RIF, !walk_q_lds(WALK)>(ix, natural_view(q, NB), act_pid, act_dist, na, 0, mid);
+    } else {
+        mid();
+        dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -749,16 +762,16 @@ struct Counters {
 // ---------------------------------------------------------------------------
 constexpr uint32_t kQuadExit = 0xFFFFFFFFu;
 struct QuadCtl { uint32_t na; uint32_t pad[3]; };
-template <int NB, int RS, int TAIL>
+template <int NB, int RS, int TAIL, class Mid = NoMid>
 __device__ __forceinline__ void quad_dist_pass(const IndexView& ix, const float* q, QuadCtl* ctl, const uint32_t* act_pid,
-                                               uint32_t* act_dist, int na) {
+                                               uint32_t* act_dist, int na, Mid mid = Mid()) {
     if (na <= 8) {                                                     // a single round: not worth two barriers
-        dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0);
+        dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0, mid);
         return;
     }
     if (lane_id() == 0) ctl->na = (uint32_t)na;
     block_sync();                                                      // B1
-    dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0);
+    dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0, mid);
     block_sync();                                                      // B2
 }
 template <int NB, int RS, int TAIL>
@@ -941,8 +954,13 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             bool fresh = false;
             int tab_idx = -1;
             visited_begin(vis);
+            // While the on-chip set takes new ids, an expansion only LOOKS its neighbours up here; the new ones are
+            // inserted while their rows are in flight (`mid` below) — rows never hold duplicates (validated on import,
+            // impossible in a built graph), so "not in the set" is final.  Every other configuration inserts at once.
+            const bool defer = vis.tab != nullptr && !vis.spill;
             if (is_nb) {
                 if (nb_pid >= ix.n) st.status |= kStBadRow;
+                else if (defer) fresh = !tab_find(vis, nb_pid);
                 else fresh = visited_insert(vis, nb_pid, tab_idx);
             }
             const uint64_t fm = __ballot(fresh);
@@ -954,8 +972,9 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 if (fresh) act_pid[my] = nb_pid;                                        // keeps slot order
                 wave_sync();
                 [[maybe_unused]] const uint32_t tk1 = IDIST_TICK();
-                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, na);
-                else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na);     // :709-710
+                auto mid = [&]() { if (defer && fresh) tab_idx = tab_insert(vis, nb_pid); };
+                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, na, mid);
+                else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na, mid);     // :709-710
                 wave_sync();
 #ifdef IDIST_PHASES
                 const uint32_t tk2 = IDIST_TICK();
