@@ -548,32 +548,69 @@ __device__ __forceinline__ void visited_note(const Visited& v, uint32_t pid) {
     atomicOr(&v.dirty[blk >> 5], 1u << (blk & 31u));
     if (v.bloom) bloom_set(v, pid);
 }
-// The set is cut into buckets of four ids (one ds_read_b128): a lookup reads whole buckets from the id's home bucket
-// on, an insert claims the first empty entry of the first bucket that has one (ds_cmpst; lanes of a wave insert
-// distinct ids concurrently, the loser of a race reads the bucket again).  Buckets fill front to back and never
-// lose an entry before the next clear, so "this bucket has an empty entry" ends a lookup: the id is not in the set.
-__device__ __forceinline__ uint32_t tab_bucket(const Visited& v, uint32_t pid) { return (pid * 0x9E3779B1u) >> v.tshift; }
-// insert pid into the LDS set: its index if it was new, -1 if it was there already
+// The set is cut into buckets of four ids (one ds_read_b128).  Every id has TWO home buckets (two hashes): a lookup
+// reads both at once — one LDS round trip, no probe loop — and an insert goes to the emptier one (first empty entry,
+// ds_cmpst; lanes of a wave insert distinct ids concurrently, the loser of a race looks again).  Buckets fill front to
+// back and never lose an entry before the next clear.  Only an id that finds BOTH home buckets full overflows: into
+// the first bucket with room on the linear chain behind its second home bucket; so a lookup walks that chain only
+// while both home buckets are full, and "this bucket has an empty entry" ends the walk.  (With one home bucket and
+// linear probing the longest chain among the 64 lanes of an expansion set the pace: 5-8 dependent LDS round trips
+// at 70 % load.)
+__device__ __forceinline__ uint32_t tab_hash1(uint32_t pid, uint32_t shift) { return (pid * 0x9E3779B1u) >> shift; }
+__device__ __forceinline__ uint32_t tab_hash2(uint32_t pid, uint32_t shift) { return ((pid ^ (pid >> 15)) * 0x85EBCA6Bu + 0xC2B2AE35u) >> shift; }
+__device__ __forceinline__ int bucket_find(const uint4 e, uint32_t pid) {
+    return e.x == pid ? 0 : (e.y == pid ? 1 : (e.z == pid ? 2 : (e.w == pid ? 3 : -1)));
+}
+__device__ __forceinline__ int bucket_fill(const uint4 e) {      // entries in use = index of the first empty one
+    return e.x == kInvalid ? 0 : (e.y == kInvalid ? 1 : (e.z == kInvalid ? 2 : (e.w == kInvalid ? 3 : 4)));
+}
+// index of pid in a set stored at T (bmask + 1 buckets, hashes shifted by bshift), -1 if it is not there
+__device__ __forceinline__ int tabset_index(const uint32_t* T, uint32_t bmask, uint32_t bshift, uint32_t pid) {
+    const uint32_t b1 = tab_hash1(pid, bshift), b2 = tab_hash2(pid, bshift);
+    const uint4 e1 = *reinterpret_cast<const uint4*>(T + 4u * b1);
+    const uint4 e2 = *reinterpret_cast<const uint4*>(T + 4u * b2);
+    int k = bucket_find(e1, pid);
+    if (k >= 0) return (int)(4u * b1) + k;
+    k = bucket_find(e2, pid);
+    if (k >= 0) return (int)(4u * b2) + k;
+    if (e1.w == kInvalid || e2.w == kInvalid) return -1;       // a home bucket has room: the id never overflowed
+    uint32_t b = (b2 + 1u) & bmask;
+    for (uint32_t probe = 0; probe <= bmask; probe++) {
+        const uint4 e = *reinterpret_cast<const uint4*>(T + 4u * b);
+        k = bucket_find(e, pid);
+        if (k >= 0) return (int)(4u * b) + k;
+        if (e.w == kInvalid) return -1;
+        b = (b + 1u) & bmask;
+    }
+    return -1;
+}
+__device__ __forceinline__ int tab_index(const Visited& v, uint32_t pid) { return tabset_index(v.tab, v.tmask, v.tshift, pid); }
+__device__ __forceinline__ bool tab_find(const Visited& v, uint32_t pid) { return tab_index(v, pid) >= 0; }
+// insert pid into the LDS set: its index if it was new, -1 if it was there already.  The set is never full
+// (frozen at 7/8, visited_begin), so the overflow walk ends.
 __device__ __forceinline__ int tab_insert(const Visited& v, uint32_t pid) {
-    uint32_t b = tab_bucket(v, pid);
+    const uint32_t b1 = tab_hash1(pid, v.tshift), b2 = tab_hash2(pid, v.tshift);
     for (;;) {
-        const uint4 e = *reinterpret_cast<const uint4*>(v.tab + 4u * b);
-        if (e.x == pid || e.y == pid || e.z == pid || e.w == pid) return -1;
-        const int k = e.x == kInvalid ? 0 : (e.y == kInvalid ? 1 : (e.z == kInvalid ? 2 : (e.w == kInvalid ? 3 : 4)));
-        if (k == 4) { b = (b + 1u) & v.tmask; continue; }
+        const uint4 e1 = *reinterpret_cast<const uint4*>(v.tab + 4u * b1);
+        const uint4 e2 = *reinterpret_cast<const uint4*>(v.tab + 4u * b2);
+        if (bucket_find(e1, pid) >= 0 || bucket_find(e2, pid) >= 0) return -1;
+        const int f1 = bucket_fill(e1), f2 = bucket_fill(e2);
+        uint32_t b = f2 < f1 ? b2 : b1;
+        int k = f2 < f1 ? f2 : f1;
+        if (k == 4) {                                           // both full: first bucket with room behind the second home
+            b = (b2 + 1u) & v.tmask;
+            for (;;) {
+                const uint4 e = *reinterpret_cast<const uint4*>(v.tab + 4u * b);
+                if (bucket_find(e, pid) >= 0) return -1;
+                k = bucket_fill(e);
+                if (k < 4) break;
+                b = (b + 1u) & v.tmask;
+            }
+        }
         const uint32_t old = atomicCAS(&v.tab[4u * b + (uint32_t)k], kInvalid, pid);
         if (old == kInvalid) return (int)(4u * b) + k;
         if (old == pid) return -1;
-        // another lane claimed the entry (a different id: a row never holds duplicates): look at the bucket again
-    }
-}
-__device__ __forceinline__ bool tab_find(const Visited& v, uint32_t pid) {
-    uint32_t b = tab_bucket(v, pid);
-    for (;;) {
-        const uint4 e = *reinterpret_cast<const uint4*>(v.tab + 4u * b);
-        if (e.x == pid || e.y == pid || e.z == pid || e.w == pid) return true;
-        if (e.w == kInvalid) return false;                      // buckets fill front to back
-        b = (b + 1u) & v.tmask;
+        // another lane claimed the entry (a different id: a row never holds duplicates): look again
     }
 }
 // Visited::clear (core/types.rs:48-58): empty the on-chip set / zero the dirty blocks.  Wave-uniform control flow.
@@ -671,19 +708,6 @@ struct DistLog {
     uint64_t* log;      // HBM [ids the set holds]: dist_bits << 32 | index in the set; nullptr = nothing is logged
     uint32_t n;         // entries (wave-uniform)
 };
-// index of pid in the on-chip set, -1 if it is not there
-__device__ __forceinline__ int tab_index(const Visited& v, uint32_t pid) {
-    uint32_t b = tab_bucket(v, pid);
-    for (;;) {
-        const uint4 e = *reinterpret_cast<const uint4*>(v.tab + 4u * b);
-        if (e.x == pid) return (int)(4u * b);
-        if (e.y == pid) return (int)(4u * b + 1u);
-        if (e.z == pid) return (int)(4u * b + 2u);
-        if (e.w == pid) return (int)(4u * b + 3u);
-        if (e.w == kInvalid) return -1;
-        b = (b + 1u) & v.tmask;
-    }
-}
 // wave-collective: lanes with idx >= 0 (the id's index in the on-chip set) log their distance
 __device__ __forceinline__ void dlog_append(DistLog& L, int idx, uint32_t dist_bits) {
     const uint64_t m = __ballot(idx >= 0);
@@ -721,17 +745,8 @@ __device__ __forceinline__ void dlog_publish(const DistLog& L, const Visited& v,
 }
 // step B: d(new, pid) from the published set of `new`'s descent, kDlogMiss if it is not there
 __device__ __forceinline__ uint32_t dlog_find(const uint32_t* P, const uint32_t* D, uint32_t bmask, uint32_t bshift, uint32_t pid) {
-    uint32_t b = (pid * 0x9E3779B1u) >> bshift;
-    for (uint32_t probe = 0; probe <= bmask; probe++) {
-        const uint4 e = *reinterpret_cast<const uint4*>(P + 4u * b);
-        if (e.x == pid) return D[4u * b];
-        if (e.y == pid) return D[4u * b + 1u];
-        if (e.z == pid) return D[4u * b + 2u];
-        if (e.w == pid) return D[4u * b + 3u];
-        if (e.w == kInvalid) return kDlogMiss;
-        b = (b + 1u) & bmask;
-    }
-    return kDlogMiss;
+    const int i = tabset_index(P, bmask, bshift, pid);
+    return i >= 0 ? D[i] : kDlogMiss;
 }
 
 struct Counters {
