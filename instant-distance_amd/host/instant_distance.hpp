@@ -73,21 +73,23 @@ public:
 private:
     template <class P> friend class Hnsw;
     template <class P, class V> friend class HnswMap;
-    idist_search_ctx* bind(const idist_index* idx) {
-        if (owner_ != idx) {
+    // The context belongs to ONE Hnsw object, recognised by its uid — an address alone would accept a new index that
+    // happens to live where a freed one did.  One query slot: Search::default() per thread must cost kilobytes.
+    idist_search_ctx* bind(const idist_index* idx, uint64_t uid) {
+        if (owner_uid_ != uid || !ctx_) {
             release();
-            check(idist_search_ctx_new(idx, 0, &ctx_));
-            owner_ = idx;
+            check(idist_search_ctx_new(idx, 1, &ctx_));
+            owner_uid_ = uid;
         }
         return ctx_;
     }
     void release() {
         if (ctx_) idist_search_ctx_free(ctx_);
         ctx_ = nullptr;
-        owner_ = nullptr;
+        owner_uid_ = 0;
     }
     idist_search_ctx* ctx_ = nullptr;
-    const idist_index* owner_ = nullptr;
+    uint64_t owner_uid_ = 0;
     std::vector<uint32_t> pid_;
     std::vector<float> dist_;
 };
@@ -209,7 +211,7 @@ public:
             for (uint32_t i = 0; i < n; i++) (*out_ids)[i] = PointId{out[i]};
         }
     }
-    Hnsw(Hnsw&& o) noexcept : idx_(o.idx_), points_(std::move(o.points_)), ef_search_(o.ef_search_) { o.idx_ = nullptr; }
+    Hnsw(Hnsw&& o) noexcept : idx_(o.idx_), uid_(o.uid_), points_(std::move(o.points_)), ef_search_(o.ef_search_) { o.idx_ = nullptr; }
     Hnsw(const Hnsw&) = delete;
     ~Hnsw() { idist_index_free(idx_); }
 
@@ -236,11 +238,13 @@ private:
         std::vector<uint32_t> pid(ef ? ef : 1);
         std::vector<float> dist(ef ? ef : 1);
         uint32_t cnt = 0;
-        check(idist_search_batch(idx_, s.bind(idx_), q.data(), 1, pid.data(), dist.data(), &cnt, nullptr));
+        check(idist_search_batch(idx_, s.bind(idx_, uid_), q.data(), 1, pid.data(), dist.data(), &cnt, nullptr));
         s.pid_.assign(pid.begin(), pid.begin() + cnt);
         s.dist_.assign(dist.begin(), dist.begin() + cnt);
     }
     idist_index* idx_ = nullptr;
+    static uint64_t next_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1); }
+    uint64_t uid_ = next_uid();        // identity of this device index for the Search objects bound to it
     std::vector<P> points_;
     uint32_t ef_search_ = 100;
 };
