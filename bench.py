@@ -213,8 +213,8 @@ def main():
         # HBM bytes per launch come from separate `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` passes over this same command
         # (scripts/profile_bench.sh; PMC passes cannot run inside the timed process) — the committed result is quoted
         traffic, traffic_source = None, None
-        for tp in ("traffic_r02.json", "traffic_r01.json"):
-            tp = os.path.join(ROOT, "profiles", tp)
+        import glob
+        for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):   # newest round first
             if os.path.exists(tp):
                 try:
                     traffic = json.load(open(tp)).get("search_kernel_hbm_bytes_per_launch")
@@ -239,6 +239,11 @@ def main():
                   "note": "nq = 1 per launch (the reference's scalar Hnsw::search); cpu = one oracle thread"}
         # the C ABI's host-pointer call: queries from host memory, results back to host memory (PCIe inclusive), never `value`
         q_host = d_q.cpu().numpy()
+        hnsw.search_batch(q_host[:1], search)
+        t0 = time.perf_counter()
+        for i in range(lat_n):
+            hnsw.search_batch(q_host[i:i + 1], search)
+        single["gpu_wall_ms_host_pointers"] = round((time.perf_counter() - t0) / lat_n * 1e3, 4)
         hnsw.search_batch(q_host, search)
         t0 = time.perf_counter()
         for _ in range(3):
