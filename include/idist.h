@@ -78,7 +78,9 @@ typedef struct idist_config {
     uint32_t ef_construction;   /* Builder::ef_construction, default 100 */
     float ml;                   /* Builder::ml, default 1/ln(32) */
     int32_t has_heuristic;      /* Builder::select_heuristic(Some/None), default Some */
-    int32_t extend_candidates;  /* Heuristic::extend_candidates, default false */
+    int32_t extend_candidates;  /* Heuristic::extend_candidates, default false.  true: core/lib.rs:648-664 without the
+                                   locks that make it deadlock upstream (:649 vs :438) = the oracle's restatement;
+                                   the build is then sequential whatever max_batch says (one insertion per launch) */
     int32_t keep_pruned;        /* Heuristic::keep_pruned, default true */
     int32_t metric;             /* IDIST_METRIC_* (the Point::distance the caller would supply) */
     uint32_t max_batch;         /* build scheduling: 1 = strictly sequential insertion (the

@@ -115,10 +115,6 @@ idist_status validate_config(const idist_config* cfg, bool for_build) {
     if (for_build) {
         if (cfg->ef_construction == 0 || cfg->ef_construction > IDIST_MAX_EF)
             return fail(IDIST_ERR_INVALID_ARG, "ef_construction %u out of [1,%u]", cfg->ef_construction, IDIST_MAX_EF);
-        if (cfg->extend_candidates)
-            return fail(IDIST_ERR_UNSUPPORTED,
-                        "Heuristic::extend_candidates=true is not implemented (it deadlocks in the reference: "
-                        "core/lib.rs:649 read-locks a node write-locked at :438)");
     }
     return IDIST_OK;
 }
@@ -329,7 +325,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     const idist_config& cfg = ix->cfg;
     const uint32_t top = ix->n_upper;
     // a step never holds more than 1/32 of the points already inserted, so scratch is sized by that
-    const uint32_t cap = std::min<uint32_t>(cfg.max_batch == 0 ? 8192u : cfg.max_batch, std::max<uint32_t>(1u, n / 32u));
+    // Heuristic::extend_candidates: defined by the oracle's lock-free restatement (it deadlocks in the reference,
+    // core/lib.rs:649 vs :438), one whole insertion per launch in program order — always the sequential schedule
+    const bool ext = cfg.has_heuristic && cfg.extend_candidates;
+    const uint32_t cap = ext ? 1u : std::min<uint32_t>(cfg.max_batch == 0 ? 8192u : cfg.max_batch, std::max<uint32_t>(1u, n / 32u));
     // the descents keep their visited set on chip, one wave per SIMD (4 per CU), like the search walk
     const uint32_t slots = std::min(cap, (uint32_t)ix->n_cu * 4u);
     const VisGeom vg = vis_geometry(n);
@@ -360,6 +359,11 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     const size_t smemA2 = smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction);
     if (smemA2 > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim %u / ef_construction %u need %zu B of LDS per wave in the build (> 64 KiB)", ix->dim, cfg.ef_construction, smemA2);
 
+    uint64_t* d_ext_work = nullptr;
+    uint32_t ext_cap = 1;
+    while (ext_cap < (cfg.ef_construction + 1u) * 65u + 64u) ext_cap <<= 1;       // a selection's working set, padded for the sort
+    const size_t smemX = smem_bytes_extend(ix->L.stride, wcap, 1u << tab_log2, vg.dirty_words);
+    if (ext && smemX > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave with extend_candidates (> 64 KiB)", smemX);
     uint32_t* d_vis = nullptr;
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
@@ -387,6 +391,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     hipEvent_t evA[2] = {nullptr, nullptr}, evS[2] = {nullptr, nullptr};
     auto release = [&]() {
         hipFree(d_zero2);
+        hipFree(d_ext_work);
         if (s1) hipStreamDestroy(s1);
         if (s2) hipStreamDestroy(s2);
         for (int i = 0; i < 2; i++) { if (evA[i]) hipEventDestroy(evA[i]); if (evS[i]) hipEventDestroy(evS[i]); }
@@ -404,6 +409,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
             return fail(IDIST_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
         }                                                                                           \
     } while (0)
+    if (ext) BCHK(hipMalloc((void**)&d_ext_work, (size_t)ext_cap * 8));
     BCHK(hipMalloc((void**)&d_vis, (size_t)slots * vg.slot_words * 4));
     BCHK(hipMemset(d_vis, 0, (size_t)slots * vg.slot_words * 4));
     BCHK(hipMalloc((void**)&d_nbr_dist, (size_t)n * IDIST_M2 * 4));
@@ -548,7 +554,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
         auto kA2 = build_select_kernel<NB_, RS_, TAIL_>;                                           \
-        if (classic) { IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA); }                         \
+        auto kX = build_extend_kernel<NB_, RS_, TAIL_>;                                            \
+        if (ext) { IDIST_LAUNCH(kX, 1, 64, smemX, sA, viewA, aA, d_ext_work, ext_cap); }           \
+        else if (classic) { IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA); }                    \
         else { IDIST_LAUNCH(kAo, gridA, 64, smem, sA, viewA, aA); }                                \
         if (pipe) {                                                                                \
             BCHK(hipEventRecord(evA[par], s1));                                                    \
@@ -556,7 +564,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
             IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s2, zbuf[par ^ 1], zbuf[par], a.touched, smallS, prev_start, prev_count); \
             BCHK(hipMemsetAsync(smallS, 0, 24, s2));                                               \
         }                                                                                          \
-        if (cfg.has_heuristic) {                                                                   \
+        if (ext) {                                                                                 \
+        } else if (cfg.has_heuristic) {                                                            \
             IDIST_LAUNCH(kA2, gridA2, 64, smemA2, sS, viewS, aS);                                  \
             IDIST_LAUNCH(kF, gridB, 64, smemF, sS, viewS, af);                                     \
             IDIST_LAUNCH(kB, gridS, 64, smemB, sS, viewS, aS);                                     \

@@ -402,6 +402,47 @@ __device__ __forceinline__ void emit_new_node(const IndexView& ix, const BuildAr
     }
 }
 
+// Construction::insert up to the end of the layer search (core/lib.rs:442-461): the new point's row into the LDS query
+// tile, the descent from the top layer, ef_construction from the insertion layer down.  Leaves Search.nearest in st.W and
+// the insertion layer's visited set in `vis`.
+template <int NB, int RS, int TAIL, int LAT>
+__device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildArgs& a, const Smem& sm, WState& st, Visited& vis,
+                                               uint32_t nw_pid, Counters& tot, DistLog& dl) {
+    const int lane = lane_id();
+    wave_sync();
+    // point = &points[new] (:442): rows are stored blocked already
+    const float* prow = ix.points + (size_t)nw_pid * ix.stride;
+    for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+        *reinterpret_cast<float4*>(sm.q + o) = *reinterpret_cast<const float4*>(prow + o);
+    wave_sync();
+    // search.reset(), :443: the visited set was emptied when the slot's previous descent ended
+    push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, dl);  // :444
+    const int num = a.layer == 0 ? kM2 : kM;                      // :445
+    for (int cur = (int)a.top;; cur--) {                          // :447
+        st.ef = cur <= (int)a.layer ? (int)a.efc : 1;             // :448-452
+        if (cur > (int)a.layer) {                                 // :453-457
+            const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
+            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dl);
+            w_cull(st);
+            visited_clear(vis);
+            visited_begin(vis, (uint32_t)st.plen);
+            for (int i = lane; i < st.plen; i += 64) visited_mark(vis, (uint32_t)st.W[i]);
+            visited_added(vis, (uint32_t)st.plen);
+            wave_sync();
+            dl.n = 0;                                             // the set was emptied: its indices start over
+            if (dl.log)
+                for (int i0 = 0; i0 < st.plen; i0 += 64) {
+                    const bool on = i0 + lane < st.plen;
+                    const uint64_t k = on ? st.W[i0 + lane] & kKeyMask : 0ull;
+                    dlog_append(dl, on ? tab_index(vis, (uint32_t)k) : -1, (uint32_t)(k >> 32));
+                }
+        } else {                                                  // :458-461
+            search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dl);
+            break;
+        }
+    }
+}
+
 template <int NB, int RS, int TAIL, int LAT = 0>
 __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(IndexView ix, BuildArgs a) {
     IDIST_DYN_SMEM(smem_raw);
@@ -421,42 +462,10 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
         item = uniform_u32(item);
         if (item >= a.count) break;
         const uint32_t nw_pid = a.start + item;
-        wave_sync();
-        // point = &points[new] (:442): rows are stored blocked already
-        const float* prow = ix.points + (size_t)nw_pid * ix.stride;
-        for (uint32_t o = lane * 4; o < ix.stride; o += 256)
-            *reinterpret_cast<float4*>(sm.q + o) = *reinterpret_cast<const float4*>(prow + o);
-        wave_sync();
-
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
         // only the heuristic's re-selections look distances up
         DistLog dl{a.has_heuristic && a.use_dlog ? a.dlog_log + ((size_t)item << a.tab_log2) : nullptr, 0u};
-        // search.reset(), :443: the visited set was emptied when the slot's previous descent ended
-        push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, dl);  // :444
-        const int num = a.layer == 0 ? kM2 : kM;                      // :445
-        for (int cur = (int)a.top;; cur--) {                          // :447
-            st.ef = cur <= (int)a.layer ? (int)a.efc : 1;             // :448-452
-            if (cur > (int)a.layer) {                                 // :453-457
-                const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-                search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dl);
-                w_cull(st);
-                visited_clear(vis);
-                visited_begin(vis, (uint32_t)st.plen);
-                for (int i = lane; i < st.plen; i += 64) visited_mark(vis, (uint32_t)st.W[i]);
-                visited_added(vis, (uint32_t)st.plen);
-                wave_sync();
-                dl.n = 0;                                             // the set was emptied: its indices start over
-                if (dl.log)
-                    for (int i0 = 0; i0 < st.plen; i0 += 64) {
-                        const bool on = i0 + lane < st.plen;
-                        const uint64_t k = on ? st.W[i0 + lane] & kKeyMask : 0ull;
-                        dlog_append(dl, on ? tab_index(vis, (uint32_t)k) : -1, (uint32_t)(k >> 32));
-                    }
-            } else {                                                  // :458-461
-                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dl);
-                break;
-            }
-        }
+        insert_descent<NB, RS, TAIL, LAT>(ix, a, sm, st, vis, nw_pid, tot, dl);
         const int nw = st.plen < st.ef ? st.plen : st.ef;             // Search.nearest
         if (a.has_heuristic) {
             // select_heuristic (:470-472) runs in step A2 with the selected rows on chip; hand Search.nearest over
@@ -481,6 +490,213 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
             atomicAdd(&a.stats[1], (unsigned long long)tot.n_exp0);
             atomicAdd(&a.stats[2], (unsigned long long)tot.n_expU);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Heuristic { extend_candidates: true } (core/lib.rs:648-664).
+//
+// In the reference this option cannot run: `select_heuristic` read-locks every candidate's node (:649,
+// core/types.rs:145-149) while `add_neighbor_heuristic` has pushed the NEW node (:626), whose write lock the inserting
+// thread holds since :438 — parking_lot locks are not re-entrant, so the second insert deadlocks.  What it WOULD
+// compute is well defined once the locks are ignored; the oracle restates exactly that (oracle/idist_oracle.c,
+// select_heuristic with extend_candidates, construction_insert with node[i] visible at once), and this kernel is the
+// device side of the same definition: one wave performs one whole insertion in program order — descent, the new point's
+// selection over {nearest} U {their unvisited zero-layer neighbours}, then for each found neighbour the re-selection
+// over {new, its row} U {their unvisited neighbours}, ZeroNode::rewrite, node.set.  Sequential by construction
+// (idist_config.max_batch is ignored), byte-identical to the oracle; a correctness path, not a fast one: the working
+// set of one selection holds up to 65 * ef_construction candidates and is sorted in HBM scratch.
+// ---------------------------------------------------------------------------
+// ascending bitonic sort of n (a power of two) keys in global memory by one wave; each pass touches every pair once
+__device__ __forceinline__ void wave_sort_u64(uint64_t* a, uint32_t n) {
+    const uint32_t lane = (uint32_t)lane_id();
+    for (uint32_t k = 2; k <= n; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = lane; i < n; i += 64) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint64_t x = a[i], y = a[l];
+                    if ((x > y) == ((i & k) == 0u)) { a[i] = y; a[l] = x; }
+                }
+            }
+            visited_drain();                                   // the pass's stores have landed before the next one reads
+            wave_sync();
+        }
+}
+
+// Search::select_heuristic(extend_candidates = true) for the point whose blocked row sits in the LDS tile q.
+// nearest[0..nn): Search.nearest (sorted keys, flags cleared); vis: Search.visited as the caller left it (:651).
+// Result: sel[0..return) = selected-then-backfilled keys (NOT re-sorted).  q2: LDS tile for one candidate row.
+template <int NB, int RS, int TAIL>
+__device__ __forceinline__ int select_extend(const IndexView& ix, const float* q, float* q2, const uint64_t* nearest, int nn,
+                                             Visited& vis, uint64_t* work, uint32_t work_cap, bool keep_pruned, uint64_t* sel,
+                                             uint64_t* disc, uint32_t* act_pid, uint32_t* act_dist, HeurCounters& hc,
+                                             uint32_t& status) {
+    const int lane = lane_id();
+    // working = nearest + every not yet visited zero-layer neighbour of its members, :643-660
+    uint32_t m = (uint32_t)nn;
+    for (int i = lane; i < nn; i += 64) work[i] = nearest[i];
+    for (int i = 0; i < nn; i++) {
+        const uint32_t cpid = (uint32_t)nearest[i];
+        const uint32_t nb = ix.zero[(size_t)cpid * kM2 + lane];                     // layer.nearest_iter(candidate.pid), :649
+        const uint64_t inval = __ballot(nb == kInvalid);
+        const int nvalid = inval ? __builtin_ctzll(inval) : 64;
+        bool fresh = false;
+        int tab_idx = -1;
+        visited_begin(vis);
+        if (lane < nvalid) {
+            if (nb >= ix.n) status |= kStBadRow;
+            else fresh = visited_insert(vis, nb, tab_idx);                           // :650
+        }
+        const uint64_t fm = __ballot(fresh);
+        const int na = __popcll(fm);
+        visited_added(vis, (uint32_t)na);
+        wave_sync();
+        if (!na) continue;
+        const int my = __popcll(fm & ((1ull << lane) - 1ull));
+        if (fresh) act_pid[my] = nb;
+        wave_sync();
+        dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);                     // :654-657
+        wave_sync();
+        hc.n_dist += (uint32_t)na;
+        if (m + (uint32_t)na > work_cap) { status |= kStGuard; break; }
+        if (fresh) work[m + (uint32_t)my] = ((uint64_t)act_dist[my] << 32) | nb;
+        m += (uint32_t)na;
+    }
+    uint32_t np2 = 1;
+    while (np2 < m) np2 <<= 1;
+    for (uint32_t i = m + (uint32_t)lane; i < np2; i += 64) work[i] = ~0ull;
+    visited_drain();
+    wave_sync();
+    if (np2 > 1) wave_sort_u64(work, np2);                                           // working.sort_unstable(), :662-664
+    // :666-685
+    int nsel = 0, ndisc = 0;
+    for (uint32_t w = 0; w < m && nsel < kM2; w++) {
+        const uint64_t c = work[w];
+        const uint32_t cpid = (uint32_t)c, cd = (uint32_t)(c >> 32);
+        bool pruned = false;
+        if (nsel > 0) {
+            wave_sync();
+            const float* prow = ix.points + (size_t)cpid * ix.stride;                // candidate_point, :675
+            for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+                *reinterpret_cast<float4*>(q2 + o) = *reinterpret_cast<const float4*>(prow + o);
+            if (lane < nsel) act_pid[lane] = (uint32_t)sel[lane];
+            wave_sync();
+            dist_rounds<NB, RS, TAIL>(ix, q2, act_pid, act_dist, nsel);              // :676-679
+            wave_sync();
+            hc.n_dist += (uint32_t)nsel;
+            pruned = __ballot(lane < nsel && act_dist[lane] < cd) != 0ull;           // OrderedFloat order == order of the canonical bits
+        }
+        wave_sync();
+        if (!pruned) {                                                               // :681-684
+            if (lane == 0) sel[nsel] = c;
+            nsel++;
+        } else if (ndisc < kM2) {                                                    // only the first 64 can ever be back-filled
+            if (lane == 0) disc[ndisc] = c;
+            ndisc++;
+        }
+    }
+    wave_sync();
+    if (keep_pruned)                                                                 // :687-695
+        for (int i = 0; i < ndisc && nsel < kM2; i++) {
+            if (lane == 0) sel[nsel] = disc[i];
+            nsel++;
+        }
+    wave_sync();
+    return nsel;
+}
+
+__host__ __device__ inline size_t smem_bytes_extend(uint32_t stride, uint32_t wcap, uint32_t tab_words, uint32_t dirty_words) {
+    return smem_bytes(stride, wcap, true, tab_words, dirty_words) + (size_t)stride * 4 + (size_t)((wcap + 1u) & ~1u) * 8 + 64 * 8;
+}
+
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(64) void build_extend_kernel(IndexView ix, BuildArgs a, uint64_t* work, uint32_t work_cap) {
+    IDIST_DYN_SMEM(smem_raw);
+    const Smem sm = carve(smem_raw, ix.stride, a.wcap, true, a.vis.dirty_words);
+    uint64_t* sel = sm.aux + 64 + 8;
+    uint64_t* disc = sel + 64;
+    float* q2 = reinterpret_cast<float*>(sm.bloom + (1u << a.tab_log2));             // behind the on-chip visited set
+    uint64_t* W2 = reinterpret_cast<uint64_t*>(q2 + ix.stride);                      // the `insertion` Search's nearest
+    uint64_t* own = W2 + ((a.wcap + 1u) & ~1u);                                      // `found`, :465-472
+    const int lane = lane_id();
+    constexpr int LAT = walk_code(kWalkClassic, 0, false, 1, true);
+    Visited vis{a.visited, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words, nullptr, 0};
+    visited_attach_tab(vis, sm.bloom, a.tab_log2);
+    for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
+    visited_clear(vis);
+    uint32_t status = 0;
+    Counters tot{0, 0, 0};
+    HeurCounters hc{0, 0};
+    const uint32_t nw_pid = a.start;                                                 // one insertion per launch
+    WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
+    DistLog nolog{nullptr, 0u};
+    insert_descent<NB, RS, TAIL, LAT>(ix, a, sm, st, vis, nw_pid, tot, nolog);       // :442-461
+    const int nn = st.plen < st.ef ? st.plen : st.ef;
+    for (int i = lane; i < nn; i += 64) sm.W[i] &= kKeyMask;
+    wave_sync();
+    status |= st.status;
+    // :470-472 for the new point; search.visited is the insertion layer's
+    const int nf = select_extend<NB, RS, TAIL>(ix, sm.q, q2, sm.W, nn, vis, work, work_cap, a.keep_pruned != 0, sel, disc,
+                                               sm.act_pid, sm.act_dist, hc, status);
+    if (lane < nf) own[lane] = sel[lane];
+    wave_sync();
+    for (int i = 0; i < nf; i++) {                                                   // :481-516
+        const uint32_t pid = (uint32_t)own[i];
+        wave_sync();
+        const float* prow = ix.points + (size_t)pid * ix.stride;                     // old = &points[pid], :484
+        for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+            *reinterpret_cast<float4*>(sm.q + o) = *reinterpret_cast<const float4*>(prow + o);
+        const uint32_t cur = ix.zero[(size_t)pid * kM2 + lane];                      // zero.nearest_iter(pid), :487
+        const uint64_t inval = __ballot(cur == kInvalid);
+        const int ncur = inval ? __builtin_ctzll(inval) : 64;
+        // add_neighbor_heuristic, :616-631: insertion.reset(); push(new); push(current...); select_heuristic
+        visited_clear(vis);                                                          // :625
+        WState ns{W2, 0, (int)a.efc, 0, 0u, (int)a.tie_cap};                         // insertion.ef = ef_construction, :440
+        visited_begin(vis);
+        if (lane == 0) { visited_mark(vis, nw_pid); sm.act_pid[0] = nw_pid; }
+        visited_added(vis, 1u);
+        wave_sync();
+        dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, 1);
+        wave_sync();
+        hc.n_dist += 1u;
+        w_push_keys(ns, lane == 0 ? (((uint64_t)sm.act_dist[0] << 32) | nw_pid) : kMaxKey, lane == 0);   // :626
+        bool fresh = false;
+        int tab_idx = -1;
+        visited_begin(vis);
+        if (lane < ncur) {
+            if (cur >= ix.n) status |= kStBadRow;
+            else fresh = visited_insert(vis, cur, tab_idx);
+        }
+        const uint64_t fm = __ballot(fresh);
+        const int na = __popcll(fm);
+        visited_added(vis, (uint32_t)na);
+        wave_sync();
+        if (na) {                                                                    // :627-629, slot order
+            const int my = __popcll(fm & ((1ull << lane) - 1ull));
+            if (fresh) sm.act_pid[my] = cur;
+            wave_sync();
+            dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, na);
+            wave_sync();
+            hc.n_dist += (uint32_t)na;
+            w_push_keys(ns, fresh ? (((uint64_t)sm.act_dist[my] << 32) | cur) : kMaxKey, fresh);
+        }
+        const int nres = select_extend<NB, RS, TAIL>(ix, sm.q, q2, W2, ns.plen, vis, work, work_cap, a.keep_pruned != 0, sel, disc,
+                                                     sm.act_pid, sm.act_dist, hc, status);       // :630
+        ix.zero[(size_t)pid * kM2 + lane] = lane < nres ? (uint32_t)sel[lane] : kInvalid;        // ZeroNode::rewrite, :495
+        if (lane == 0) ix.zero[(size_t)nw_pid * kM2 + i] = pid;                       // node.set(i, pid), :516
+        visited_drain();
+        wave_sync();
+    }
+    visited_clear(vis);
+    if (lane == 0) {
+        if (status) atomicOr(a.status, status);
+        atomicAdd(&a.stats[0], (unsigned long long)tot.n_dist);
+        atomicAdd(&a.stats[1], (unsigned long long)tot.n_exp0);
+        atomicAdd(&a.stats[2], (unsigned long long)tot.n_expU);
+        atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
+        atomicAdd(&a.stats[5], (unsigned long long)nf);
+        atomicAdd(&a.stats[7], (unsigned long long)nf);
     }
 }
 

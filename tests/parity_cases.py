@@ -135,16 +135,16 @@ def check_search_parity(ida, oracle, n, dim, ef_search=100, metric=0, kind="unif
 
 
 def check_build_exact(ida, oracle, n, dim, metric=0, kind="uniform", ef_construction=100, keep_pruned=True, seed=0,
-                      heuristic=True):
+                      heuristic=True, extend=False, max_batch=1, variants=None):
     """max_batch = 1: zero/layers byte-identical to the oracle's sequential build."""
     rng = np.random.default_rng(seed)
     pts = gen_points(rng, n, dim, kind)
     cfg = oracle.default_config(metric=metric, ef_construction=ef_construction, keep_pruned=int(keep_pruned),
-                                has_heuristic=int(heuristic))
+                                has_heuristic=int(heuristic), extend_candidates=int(extend))
     oix = oracle.Index.build(pts, cfg, threads=1)
-    b = (ida.Builder().metric(metric).max_batch(1).ef_construction(ef_construction)
-         .select_heuristic(ida.Heuristic(False, keep_pruned) if heuristic else None))
-    for _, lat in BUILD_VARIANTS:         # the descent of an insertion has the same variants as the search
+    b = (ida.Builder().metric(metric).max_batch(max_batch).ef_construction(ef_construction)
+         .select_heuristic(ida.Heuristic(extend, keep_pruned) if heuristic else None))
+    for _, lat in (variants or BUILD_VARIANTS):   # the descent of an insertion has the same variants as the search
         with search_variant(lat):
             h = ida.Hnsw.from_ordered_points(pts, b)
         zero, layers = h.into_parts()

@@ -119,6 +119,20 @@ def test_build_exact_small(eng, oracle, n, dim, kw):
     pc.check_build_exact(ida, oracle, n=n, dim=dim, seed=n, **kw)
 
 
+@pytest.mark.parametrize("n,dim,kw", [
+    (40, 3, {}), (70, 4, {"metric": 1}), (90, 5, {"keep_pruned": False}), (64, 300, {"ef_construction": 12}),
+    (80, 2, {"kind": "grid", "metric": 1, "ef_construction": 20}),
+])
+def test_build_exact_extend_candidates(eng, oracle, n, dim, kw):
+    """Heuristic { extend_candidates: true } (core/lib.rs:648-664).  Upstream it deadlocks on the second insert (:649 read-locks
+    a node write-locked at :438); its meaning without the locks is the oracle's restatement, and the GPU must match that byte
+    for byte.  The schedule is sequential whatever max_batch says."""
+    ida, kind = eng
+    scale = 1 if kind != "gpu" else 6
+    both = (("on-chip", {}), ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7"}))
+    pc.check_build_exact(ida, oracle, n=n * scale, dim=dim, seed=n, extend=True, max_batch=0, variants=both, **kw)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,dim,heur", [(1024, 2, True), (3000, 128, True), (2000, 300, True), (1200, 768, True),
                                         (1024, 2, False), (3000, 128, False), (1500, 300, False)])
