@@ -32,9 +32,14 @@ torch.cuda.synchronize()
 truth = None
 cases = [({}, "default"), ({"IDIST_BUILD_PIPELINE": "0"}, "one stream"),
          ({"IDIST_BUILD_PIPELINE": "0", "IDIST_BUILD_NO_DLOG": "1"}, "one stream, no distance log (step B recomputes)"),
-         ({"IDIST_BUILD_NO_DLOG": "1"}, "pipelined, no distance log"), ({"IDIST_BUILD_A_WAVES": "4"}, "4 descent waves per CU")]
+         ({"IDIST_BUILD_NO_DLOG": "1"}, "pipelined, no distance log"), ({"IDIST_BUILD_A_WAVES": "4"}, "4 descent waves per CU"),
+         ({"IDIST_BUILD_RT2": "8"}, "A2 tile of 8 selected rows"), ({"IDIST_BUILD_RT2": "4"}, "A2 tile of 4 selected rows"),
+         ({"IDIST_BUILD_RT2": "2"}, "A2 tile of 2 selected rows"), ({"IDIST_BUILD_RT2": "4", "IDIST_BUILD_A_WAVES": "4"}, "A2 tile 4, 4 descent waves"),
+         ({"IDIST_BUILD_A_WAVES": "2"}, "2 descent waves per CU"),
+         ({"IDIST_BUILD_A2_STREAM": "s"}, "step A2 on the update stream (round-1 placement)"),
+         ({"IDIST_BUILD_A_WAVES": "4"}, "4 descent waves per CU"), ({"IDIST_BUILD_CHECK": "1"}, "default + pipeline self-check")]
 if os.environ.get("PB_CASES"):
-    cases = [c for i, c in enumerate(cases) if str(i) in os.environ["PB_CASES"].split(",")]
+    cases = [cases[int(i)] for i in os.environ["PB_CASES"].split(",")]
 for env, nm in cases:
     os.environ.update(env)
     h = ida.Hnsw.from_device_points(d_pts.data_ptr(), n, dim, ida.Builder())
