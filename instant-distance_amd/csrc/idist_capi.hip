@@ -168,6 +168,7 @@ struct Knobs {
     bool bloom = true;            // IDIST_BLOOM=0 disables the LDS Bloom filter in front of the visited bitmap
     uint32_t tab_log2 = 0;        // IDIST_TAB_LOG2=<5..13>: size of the on-chip visited set (test knob: small sets exercise the overflow path)
     bool vis_bitmap = false;      // IDIST_VISITED=bitmap: search with bitmap + Bloom filter (16 waves per CU) instead of the on-chip set
+    bool vis_onchip = false;      // IDIST_VISITED=onchip: the on-chip set whatever the policy says (test / A-B knob)
     int tune = -1;                // IDIST_TUNE=<i> (tuning builds only, -DIDIST_TUNE): i-th experimental walk variant
     uint32_t quad_nq = 0xFFFFFFFFu;   // IDIST_QUAD_NQ: batches up to this many queries run four waves per query (default: one
                                       // workgroup per CU, i.e. the CU count; 0 = never)
@@ -178,7 +179,7 @@ struct Knobs {
         if (const char* e = getenv("IDIST_QUAD_NQ")) k.quad_nq = (uint32_t)std::min<unsigned long>(strtoul(e, nullptr, 10), 0xFFFFFFFEul);
         if (const char* e = getenv("IDIST_WALK")) k.classic = e[0] == 'c';
         if (const char* e = getenv("IDIST_BLOOM")) k.bloom = e[0] != '0';
-        if (const char* e = getenv("IDIST_VISITED")) k.vis_bitmap = e[0] == 'b';
+        if (const char* e = getenv("IDIST_VISITED")) { k.vis_bitmap = e[0] == 'b'; k.vis_onchip = e[0] == 'o'; }
         if (const char* e = getenv("IDIST_TAB_LOG2")) k.tab_log2 = std::min(13u, std::max(5u, (uint32_t)atoi(e)));
         return k;
     }
@@ -693,9 +694,14 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
     return IDIST_OK;
 }
 
-// A search visits ~53 * ef_search + 600 nodes (C3); the 8192-id set is frozen at 7168.  Beyond ef_search ~ 200 most of a
-// walk would run on the overflow path, where 16 bitmap waves per CU are faster (profiles/probe_r02_search_onchip_visited.jsonl)
-constexpr uint32_t kOnChipMaxEf = 192;
+// Which walk serves a wide batch (profiles/probe_r02_ef_paths_onchip_vs_bitmap.jsonl, probe_r02_configs_c2_c4_c5.jsonl):
+//   * a search visits ~53 * ef_search + 600 nodes; the 8192-id on-chip set is frozen at 7168 and the rest of the walk
+//     test-and-sets the bitmap.  The fat on-chip waves still win while a row fetch outweighs that extra round trip:
+//     up to ef_search ~ 180 at 128-d, ~ 550 at 300-d, beyond 200 at 768-d  =>  ef_search <= 1.5 x row floats;
+//   * an index that sits in the Infinity Cache (100k x 128: 51 MB) is served faster by 16 small waves per CU
+//     (4.2 vs 5.0 ms per 10k queries): the on-chip walk is for HBM-resident indexes.
+inline uint32_t on_chip_max_ef(uint32_t stride_floats) { return std::min(1536u, std::max(160u, stride_floats * 3u / 2u)); }
+constexpr size_t kCacheResidentBytes = (size_t)128 << 20;
 
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
                            uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream) {
@@ -710,17 +716,21 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // Default walk: the visited set lives in LDS (an exact hash set of 2^tab_log2 ids per query, the HBM bitmap only
     // takes what does not fit), one wave per SIMD with up to 512 registers for rows in flight.  The largest set that
     // fits a quarter of the CU's LDS next to the query tile and W is used; none fits (huge ef_search) -> bitmap walk.
-    uint32_t tab_log2 = 0;
-    if (!ctx->knobs.vis_bitmap && (ef <= kOnChipMaxEf || ctx->knobs.tab_log2))
-        for (uint32_t l = 13; l >= 10 && !tab_log2; l--)
-            if (smem_bytes(ix->L.stride, a.wcap, false, 1u << l, a.vis.dirty_words) <= kOnChipLdsPerWave) tab_log2 = l;
-    if (tab_log2 && ctx->knobs.tab_log2) tab_log2 = std::min(tab_log2, ctx->knobs.tab_log2);
-    const bool on_chip = tab_log2 != 0;
-    a.tab_log2 = tab_log2;
+    uint32_t tab_fit = 0;                                               // largest set that fits at all
+    for (uint32_t l = 13; l >= 10 && !tab_fit; l--)
+        if (smem_bytes(ix->L.stride, a.wcap, false, 1u << l, a.vis.dirty_words) <= kOnChipLdsPerWave) tab_fit = l;
+    if (tab_fit && ctx->knobs.tab_log2) tab_fit = std::min(tab_fit, ctx->knobs.tab_log2);
+    if (ctx->knobs.vis_bitmap) tab_fit = 0;
     // Narrow batches (the reference's call pattern is ONE query per Hnsw::search): a four-wave workgroup per query,
     // one workgroup per CU — the rows of an expansion are fetched by all four SIMDs in one round trip.
     const uint32_t quad_nq = ctx->knobs.quad_nq == 0xFFFFFFFFu ? (uint32_t)ix->n_cu : ctx->knobs.quad_nq;
-    const bool quad = on_chip && !ctx->knobs.classic && nq <= quad_nq;
+    const bool quad = tab_fit && !ctx->knobs.classic && nq <= quad_nq;
+    const bool cache_resident = (size_t)ix->n * ix->L.stride * 4 <= kCacheResidentBytes;
+    const bool wide_on_chip = tab_fit && (ctx->knobs.vis_onchip || ctx->knobs.tab_log2 ||
+                                          (ef <= on_chip_max_ef(ix->L.stride) && !cache_resident));
+    const bool on_chip = quad || wide_on_chip;
+    const uint32_t tab_log2 = on_chip ? tab_fit : 0u;
+    a.tab_log2 = tab_log2;
     const uint32_t resident = (uint32_t)ix->n_cu * (quad ? 1u : (on_chip ? 4u : 16u));
     CHK(ensure_slots(ctx, std::min(nq, resident), stream));
     ctx->last_ef = ef;

@@ -11,9 +11,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # Parity does not depend on where a context's visited array lands in HBM; skip the placement calibration
-    # (up to 6 candidate allocations per context) except where a test asks for it.
-    os.environ.setdefault("IDIST_VISITED_TRIES", "1")
 
 
 @pytest.fixture(scope="session")

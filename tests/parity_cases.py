@@ -14,11 +14,11 @@ INVALID = 0xFFFFFFFF
 # Variants of the graph walk (idist_device.hpp): the default keeps the visited set on chip (LDS hash set, HBM bitmap
 # as overflow — forced early with a tiny set); IDIST_VISITED=bitmap selects the bitmap + Bloom-filter walks (classic /
 # latency / overlap by batch width and IDIST_WALK).  All must give the reference's results.
-SEARCH_VARIANTS = (("default (narrow batches: four waves per query)", {}),
-                   ("on-chip", {"IDIST_QUAD_NQ": "0"}),
+SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by index size and ef_search)", {}),
+                   ("on-chip", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip"}),
                    ("four waves per query", {"IDIST_QUAD_NQ": "4000000000"}),
                    ("four waves per query, set of 128 ids then bitmap", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_LOG2": "7"}),
-                   ("on-chip classic", {"IDIST_WALK": "classic"}),
+                   ("on-chip classic", {"IDIST_WALK": "classic", "IDIST_VISITED": "onchip"}),
                    ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7", "IDIST_QUAD_NQ": "0"}),
                    ("on-chip, set of 32 ids: bitmap from the start", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}),
                    ("bitmap overlap", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "0"}),

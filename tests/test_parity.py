@@ -248,12 +248,11 @@ def test_build_batched_matches_oracle_recall_gpu(engine_loader, oracle):
 
 
 @pytest.mark.gpu
-def test_c3_full_size_properties_gpu(engine_loader, oracle, monkeypatch):
+def test_c3_full_size_properties_gpu(engine_loader, oracle):
     """BASELINE config C3 at full size (1M x 300 f32): build on the GPU, then (i) size-independent
     properties, (ii) the oracle searching the SAME exported graph must agree bit for bit, (iii) exact
-    recall against the MFMA-filtered brute force.  Runs with the placement calibration of the search context on."""
+    recall against the MFMA-filtered brute force."""
     ida = engine_loader("gpu")
-    monkeypatch.delenv("IDIST_VISITED_TRIES", raising=False)
     rng = np.random.default_rng(3)
     n, dim = 1_000_000, 300
     z = rng.standard_normal((n, 32), dtype=np.float32)
