@@ -365,6 +365,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     while (ext_cap < (cfg.ef_construction + 1u) * 65u + 64u) ext_cap <<= 1;       // a selection's working set, padded for the sort
     const size_t smemX = smem_bytes_extend(ix->L.stride, wcap, 1u << tab_log2, vg.dirty_words);
     if (ext && smemX > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave with extend_candidates (> 64 KiB)", smemX);
+    // step A2 on the matrix cores (Gram matrix of the candidates as a filter, idist_mfma.hpp) where it applies
+    const bool a2_mfma = cfg.has_heuristic && cfg.metric == IDIST_METRIC_L2SQ && cfg.ef_construction <= 128 &&
+                         !(getenv("IDIST_BUILD_A2") && getenv("IDIST_BUILD_A2")[0] == 't');
+    const size_t smemA2m = smem_bytes_select_mfma(ix->L.stride);
     uint32_t* d_vis = nullptr;
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
@@ -542,6 +546,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
             const uint32_t gridS = std::min<uint32_t>(gridB, (uint32_t)ix->n_cu * 6);
             const uint32_t gridA2 = std::min<uint32_t>(B, (uint32_t)ix->n_cu * 4);
+            const uint32_t gridA2m = std::min<uint32_t>(B, (uint32_t)ix->n_cu * 2);
             BuildArgs aS = aA;                                             // same step-A outputs, own counters
             aS.queue = smallS + 1;
             aS.n_slow = smallS + 3;
@@ -556,6 +561,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
         auto kA2 = build_select_kernel<NB_, RS_, TAIL_>;                                           \
         auto kX = build_extend_kernel<NB_, RS_, TAIL_>;                                            \
+        auto kA2m = build_select_mfma_kernel<NB_, RS_, TAIL_>;                                     \
         if (ext) { IDIST_LAUNCH(kX, 1, 64, smemX, sA, viewA, aA, d_ext_work, ext_cap); }           \
         else if (classic) { IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA); }                    \
         else { IDIST_LAUNCH(kAo, gridA, 64, smem, sA, viewA, aA); }                                \
@@ -567,7 +573,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         }                                                                                          \
         if (ext) {                                                                                 \
         } else if (cfg.has_heuristic) {                                                            \
-            IDIST_LAUNCH(kA2, gridA2, 64, smemA2, sS, viewS, aS);                                  \
+            if (a2_mfma) { IDIST_LAUNCH(kA2m, gridA2m, 256, smemA2m, sS, viewS, aS); }             \
+            else { IDIST_LAUNCH(kA2, gridA2, 64, smemA2, sS, viewS, aS); }                         \
             IDIST_LAUNCH(kF, gridB, 64, smemF, sS, viewS, af);                                     \
             IDIST_LAUNCH(kB, gridS, 64, smemB, sS, viewS, aS);                                     \
         } else {                                                                                   \

@@ -16,6 +16,7 @@
 // The result is bit-identical to bruteforce_kernel's (tests/test_parity.py::test_bruteforce_mfma*).
 #pragma once
 #include "idist_device.hpp"
+#include "idist_kernels.hpp"
 
 namespace idist {
 
@@ -218,6 +219,225 @@ __global__ __launch_bounds__(64) void rerank_kernel(IndexView ix, const float* _
             out_pid[(size_t)qi * k + i] = pid;
             out_dist[(size_t)qi * k + i] = d;
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Build step A2 on the matrix cores: Search::select_heuristic for a new point (core/lib.rs:636-698, extend_candidates
+// = false) — the one place on the build path where the distances ARE a dense contraction: the verdict on candidate i
+// needs d(c_i, c_j) for the candidates j < i that were selected, i.e. entries of the Gram matrix of the <= 128
+// candidate rows (100 x 100 x 300 at C3, per inserted point).
+//
+// The order-defining comparison is `d(c_i, c_j) < d(c_i, q)` (:676-679) with the CANONICAL distance; a product-form
+// distance |c_i|^2 + |c_j|^2 - 2 c_i.c_j rounds differently, so it is used as a filter with a margin, never as the
+// answer: with G~ from v_mfma_f32_32x32x2_f32 and eps_ij = kGramEps * K * (|c_i|^2 + |c_j|^2) (K = stored row length; the
+// f32 error of either form is below K * 2^-24 of that scale),
+//      G~ + eps <  d(c_i,q)   =>  c_j is closer for certain          (bit in closer[i])
+//      G~ - eps >= d(c_i,q)   =>  it is not, for certain
+//      otherwise              =>  uncertain: the canonical distance is computed for that pair (bit in unsure[i]).
+// The sequential part of the heuristic then is bit arithmetic on 128-bit masks; ~0.1 % of the pairs take the exact
+// path.  Results are identical to build_select_kernel's (same selected set, same order, a valid pruner per discarded
+// entry); tests run both (IDIST_BUILD_A2=tile selects the tile kernel).  Squared-L2 metric and ef_construction <= 128.
+//
+// One 256-thread workgroup per new point: the four waves share the staged K-chunks (128 rows x 32 floats) and own
+// the ten lower-triangle 32 x 32 tiles 3/3/2/2; wave 0 runs the selection.  28 KB of LDS, < 128 VGPRs.
+// ---------------------------------------------------------------------------
+constexpr int kGramRows = 128, kGramChunk = 32, kGramPitch = kGramChunk + 1;
+constexpr float kGramEps = 4.0f * 5.9604645e-8f;    // 4 * 2^-24 per stored element, times the row length at run time
+
+__host__ __device__ inline size_t smem_bytes_select_mfma(uint32_t stride) {
+    return (size_t)kGramRows * kGramPitch * 4 + 2 * kGramRows * 4 * 4 + 2 * kGramRows * 4 + kGramRows * 8 + kGramRows * 4 +
+           2 * 64 * 8 + 2 * 64 * 4 + 2 * 64 * 4 + (size_t)stride * 4 + 16;
+}
+
+// (compiled for >= 4 waves per SIMD, i.e. <= 128 registers: its waves must fit next to the 1-wave-per-SIMD descents)
+#ifdef IDIST_EMU
+#define IDIST_A2M_ATTR
+#else
+#define IDIST_A2M_ATTR __attribute__((amdgpu_waves_per_eu(4, 8)))
+#endif
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(256) IDIST_A2M_ATTR void build_select_mfma_kernel(IndexView ix, BuildArgs a) {
+    IDIST_DYN_SMEM(smem_raw);
+    float* Cs = reinterpret_cast<float*>(smem_raw);                      // [128][33] one K-chunk of every candidate row
+    uint32_t* closer = reinterpret_cast<uint32_t*>(Cs + kGramRows * kGramPitch);   // [128][4]
+    uint32_t* unsure = closer + kGramRows * 4;                           // [128][4]
+    float* norms = reinterpret_cast<float*>(unsure + kGramRows * 4);     // [128]
+    float* cdf = norms + kGramRows;                                      // [128] d(c_i, q)
+    uint64_t* keys = reinterpret_cast<uint64_t*>(cdf + kGramRows);       // [128] Search.nearest
+    uint32_t* pids = reinterpret_cast<uint32_t*>(keys + kGramRows);      // [128]
+    uint64_t* sel = reinterpret_cast<uint64_t*>(pids + kGramRows);       // [64]
+    uint64_t* disc = sel + 64;                                           // [64]
+    uint32_t* dprn = reinterpret_cast<uint32_t*>(disc + 64);             // [64]
+    uint32_t* out_aux = dprn + 64;                                       // [64]
+    uint32_t* act_pid = out_aux + 64;                                    // [64]
+    uint32_t* act_dist = act_pid + 64;                                   // [64]
+    float* qrow = reinterpret_cast<float*>(act_dist + 64);               // [stride] one candidate row (exact path)
+    uint32_t* ctl = reinterpret_cast<uint32_t*>(qrow + ix.stride);       // [4]
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = (int)uniform_u32((uint32_t)tid >> 6);
+    // lower-triangle tiles (ti, tj) of the 4 x 4 grid, by wave: w0 (0,0) (3,0) (3,1); w1 (1,0) (1,1) (3,2); w2 (2,0) (2,1);
+    // w3 (2,2) (3,3) — one nibble per tile
+    const uint32_t ti_pack = wv == 0 ? 0x330u : (wv == 1 ? 0x311u : (wv == 2 ? 0x022u : 0x032u));
+    const uint32_t tj_pack = wv == 0 ? 0x100u : (wv == 1 ? 0x210u : (wv == 2 ? 0x010u : 0x032u));
+    const int ntile = wv < 2 ? 3 : 2;
+    int kTi[3], kTj[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) { kTi[t] = (int)((ti_pack >> (4 * t)) & 15u); kTj[t] = (int)((tj_pack >> (4 * t)) & 15u); }
+    const float eps_k = kGramEps * (float)ix.stride;
+    HeurCounters hc{0, 0};
+    for (;;) {
+        if (tid == 0) ctl[0] = atomicAdd(&a.queue[4], 1u);
+        block_sync();
+        const uint32_t item = uniform_u32(ctl[0]);
+        if (item >= a.count) break;
+        const uint32_t nw_pid = a.start + item;
+        const int nw = (int)a.wcount[item];
+        for (int i = tid; i < kGramRows; i += 256) {
+            const uint64_t k = i < nw ? a.wbuf[(size_t)item * a.efc + i] : 0ull;
+            keys[i] = k;
+            pids[i] = i < nw ? (uint32_t)k : 0u;                          // padding rows re-read point 0 (never used)
+            cdf[i] = __uint_as_float((uint32_t)(k >> 32));
+        }
+        for (int i = tid; i < kGramRows * 4; i += 256) { closer[i] = 0u; unsure[i] = 0u; }
+        block_sync();
+        f32x16 acc[3];
+        for (int t = 0; t < 3; t++)
+            for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+        // ---- Gram matrix: G = C * C^T over the stored row length, one 32-float chunk at a time
+        for (uint32_t kc = 0; kc < ix.stride; kc += kGramChunk) {
+            for (int u = 0; u < 4; u++) {
+                const int idx = tid + 256 * u;                           // 1024 float4 = 128 rows x 8
+                const int row = idx >> 3, part = (idx & 7) << 2;
+                float4 v;
+                v.x = v.y = v.z = v.w = 0.0f;
+                if (kc + (uint32_t)part < ix.stride && row < nw)
+                    v = *reinterpret_cast<const float4*>(ix.points + (size_t)pids[row] * ix.stride + kc + part);
+                float* d = Cs + row * kGramPitch + part;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            block_sync();
+#pragma unroll 4
+            for (int kk = 0; kk < kGramChunk / 2; kk++) {
+                const int kcol = kk * 2 + (lane >> 5);
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    if (t < ntile && kTi[t] * 32 < nw) {
+                        const float av = Cs[(kTi[t] * 32 + (lane & 31)) * kGramPitch + kcol];
+                        const float bv = Cs[(kTj[t] * 32 + (lane & 31)) * kGramPitch + kcol];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            block_sync();
+        }
+        // ---- |c_i|^2 from the diagonal tiles: lane l holds G[x][x], x = l & 31, iff ((x >> 2) & 1) == (l >> 5), in
+        //      register ((x >> 3) << 2) | (x & 3)
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            if (t < ntile && kTi[t] == kTj[t]) {
+                const int x = lane & 31;
+                const bool has = ((x >> 2) & 1) == (lane >> 5);
+                const int rsel = ((x >> 3) << 2) | (x & 3);
+                float nv = 0.0f;
+                for (int r = 0; r < 16; r++) nv = r == rsel ? acc[t][r] : nv;
+                if (has) norms[kTi[t] * 32 + x] = nv;
+            }
+        }
+        block_sync();
+        // ---- verdict masks: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            if (t < ntile && kTi[t] * 32 < nw) {
+                const int j = kTj[t] * 32 + (lane & 31);
+                const float nj = norms[j];
+                for (int r = 0; r < 16; r++) {
+#ifndef IDIST_EMU
+                    asm volatile("" ::: "memory");                        // one row's operands at a time (keeps the kernel under 128 registers)
+#endif
+                    const int i = kTi[t] * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float ni = norms[i], cd = cdf[i];
+                    const float g = ni + nj - 2.0f * acc[t][r];
+                    const float eps = eps_k * (ni + nj);
+                    const bool valid = j < i && i < nw;
+                    const bool cl = valid && (g + eps < cd);
+                    const bool ncl = g - eps >= cd;
+                    const bool un = valid && !cl && !ncl;                 // also every NaN / inf case
+                    const uint64_t mc = __ballot(cl), mu = __ballot(un);
+                    const int i0 = kTi[t] * 32 + (r & 3) + 8 * (r >> 2);
+                    if (lane == 0) { closer[i0 * 4 + kTj[t]] = (uint32_t)mc; unsure[i0 * 4 + kTj[t]] = (uint32_t)mu; }
+                    if (lane == 32) { closer[(i0 + 4) * 4 + kTj[t]] = (uint32_t)(mc >> 32); unsure[(i0 + 4) * 4 + kTj[t]] = (uint32_t)(mu >> 32); }
+                }
+            }
+        }
+        block_sync();
+        // ---- the heuristic itself (wave 0): core/lib.rs:666-695 on the masks
+        if (wv == 0) {
+            uint32_t selm[4] = {0u, 0u, 0u, 0u};
+            int nsel = 0, ndis = 0;
+            for (int i = 0; i < nw && nsel < kM2; i++) {
+                const uint64_t c = keys[i];
+                const uint32_t cd = (uint32_t)(c >> 32);
+                bool pruned = false;
+                uint32_t pr_pid = 0;
+                for (int w = 0; w < 4 && !pruned; w++) {
+                    const uint32_t m = closer[i * 4 + w] & selm[w];
+                    if (m) { pruned = true; pr_pid = pids[w * 32 + __builtin_ctz(m)]; }
+                }
+                bool staged = false;
+                for (int w = 0; w < 4 && !pruned; w++) {                 // pairs the filter could not decide: canonical distance
+                    const uint32_t m = unsure[i * 4 + w] & selm[w];
+                    if (!m) continue;
+                    wave_sync();
+                    if (!staged) {
+                        const float* prow = ix.points + (size_t)pids[i] * ix.stride;
+                        for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+                            *reinterpret_cast<float4*>(qrow + o) = *reinterpret_cast<const float4*>(prow + o);
+                        staged = true;
+                    }
+                    const int cnt = __builtin_popcount(m);
+                    if (lane < 32 && ((m >> lane) & 1u)) act_pid[__builtin_popcount(m & ((1u << lane) - 1u))] = pids[w * 32 + lane];
+                    wave_sync();
+                    dist_rounds<-1, -1, -1>(ix, qrow, act_pid, act_dist, cnt);     // rare: the small runtime-geometry form
+                    wave_sync();
+                    hc.n_dist += (uint32_t)cnt;
+                    const uint64_t cm = __ballot(lane < cnt && act_dist[lane] < cd);   // strict <, :678
+                    if (cm) { pruned = true; pr_pid = act_pid[__builtin_ctzll(cm)]; }
+                }
+                wave_sync();
+                if (!pruned) {                                           // :681-684
+                    if (lane == 0) sel[nsel] = c;
+                    selm[i >> 5] |= 1u << (i & 31);
+                    nsel++;
+                } else {
+                    if (lane == 0 && ndis < kM2) { disc[ndis] = c; dprn[ndis] = pr_pid; }
+                    ndis++;
+                }
+            }
+            hc.n_rows += (uint32_t)nw;
+            hc.n_dist += (uint32_t)(nw * (nw - 1) / 2);                  // pairs decided (by the filter or exactly)
+            const int n_selected = nsel;
+            out_aux[lane] = 0u;
+            wave_sync();
+            if (a.keep_pruned) {                                         // :687-695
+                if (ndis > kM2) ndis = kM2;
+                int take = kM2 - nsel;
+                if (take > ndis) take = ndis;
+                if (lane < take) { sel[nsel + lane] = disc[lane]; out_aux[nsel + lane] = dprn[lane]; }
+                if (take > 0) nsel += take;
+                wave_sync();
+            }
+            if (lane == 0) a.row_nsel[nw_pid] = (uint32_t)n_selected;
+            a.nbr_aux[(size_t)nw_pid * kM2 + lane] = out_aux[lane];
+            emit_new_node(ix, a, item, nw_pid, sel, nsel);
+        }
+        block_sync();
+    }
+    if (tid == 0 && (hc.n_dist | hc.n_rows)) {
+        atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
+        atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);
     }
 }
 

@@ -37,7 +37,8 @@ cases = [({}, "default"), ({"IDIST_BUILD_PIPELINE": "0"}, "one stream"),
          ({"IDIST_BUILD_RT2": "2"}, "A2 tile of 2 selected rows"), ({"IDIST_BUILD_RT2": "4", "IDIST_BUILD_A_WAVES": "4"}, "A2 tile 4, 4 descent waves"),
          ({"IDIST_BUILD_A_WAVES": "2"}, "2 descent waves per CU"),
          ({"IDIST_BUILD_A2_STREAM": "s"}, "step A2 on the update stream (round-1 placement)"),
-         ({"IDIST_BUILD_A_WAVES": "4"}, "4 descent waves per CU"), ({"IDIST_BUILD_CHECK": "1"}, "default + pipeline self-check")]
+         ({"IDIST_BUILD_A_WAVES": "4"}, "4 descent waves per CU"), ({"IDIST_BUILD_CHECK": "1"}, "default + pipeline self-check"),
+         ({"IDIST_BUILD_A2": "tile"}, "step A2 with the LDS-tile kernel (vector FMA) instead of the Gram matrix on MFMA")]
 if os.environ.get("PB_CASES"):
     cases = [cases[int(i)] for i in os.environ["PB_CASES"].split(",")]
 for env, nm in cases:
