@@ -81,12 +81,14 @@ int main(int argc, char** argv) {
     size_t recall_simple = randomized(Builder::default_().select_heuristic(nullptr), 987654321ull, n);
     printf("simple recall = %zu\n", recall_simple);
     REQUIRE(recall_simple > 90);                   // tests/all.rs:52
-    // extend_candidates = true deadlocks in the reference; reported, not silently mis-built
-    try {
+    // extend_candidates = true deadlocks in the reference (core/lib.rs:649 vs :438); here it is defined by the oracle's
+    // lock-free restatement and builds (sequentially) — tests/test_parity.py checks the graph byte for byte
+    {
         Heuristic h{true, true};
-        randomized(Builder::default_().select_heuristic(&h), 1, 64);
-        REQUIRE(false);
-    } catch (const Error& e) { REQUIRE(e.status == IDIST_ERR_UNSUPPORTED); }
+        size_t recall_ext = randomized(Builder::default_().select_heuristic(&h), 1, 64);
+        printf("extend_candidates recall = %zu\n", recall_ext);
+        REQUIRE(recall_ext > 60);                  // 64 points, top-100 query: everything there is to find
+    }
     // Builder::progress (core/lib.rs:70-75): position ends at the length, never goes back
     {
         std::vector<std::pair<uint64_t, uint64_t>> seen;

@@ -408,9 +408,9 @@ def test_import_validation_and_unsupported(eng, oracle):
     zero[3, 1] = pc.INVALID
     zero[3, 2] = 50                         # garbage after the first INVALID is never read (core/types.rs:183-187)
     ida.Hnsw.from_parts(pts, zero, [], ida.Builder())
-    with pytest.raises(ida.IdistError) as e:
-        ida.Builder().select_heuristic(ida.Heuristic(True, True)).build_hnsw(pts)
-    assert e.value.status == 4
+    # Heuristic::extend_candidates deadlocks upstream; here it builds (test_build_exact_extend_candidates checks the graph)
+    h, _ = ida.Builder().select_heuristic(ida.Heuristic(True, True)).build_hnsw(pts)
+    assert len(h) == 50
     with pytest.raises(ida.IdistError) as e:
         ida.Builder().ef_search(5000).build_hnsw(pts)
     assert e.value.status == 1
