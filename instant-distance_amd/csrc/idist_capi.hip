@@ -170,8 +170,8 @@ struct Knobs {
     bool vis_bitmap = false;      // IDIST_VISITED=bitmap: search with bitmap + Bloom filter (16 waves per CU) instead of the on-chip set
     bool vis_onchip = false;      // IDIST_VISITED=onchip: the on-chip set whatever the policy says (test / A-B knob)
     int tune = -1;                // IDIST_TUNE=<i> (tuning builds only, -DIDIST_TUNE): i-th experimental walk variant
-    uint32_t quad_nq = 0xFFFFFFFFu;   // IDIST_QUAD_NQ: batches up to this many queries run four waves per query (default: one
-                                      // workgroup per CU, i.e. the CU count; 0 = never)
+    uint32_t quad_nq = 0xFFFFFFFFu;   // IDIST_QUAD_NQ: batches up to this many queries run four waves per query (default: two
+                                      // workgroups per CU, one for 768-d rows; 0 = never)
     static Knobs from_env() {
         Knobs k;
         if (const char* e = getenv("IDIST_TUNE")) k.tune = atoi(e);
@@ -730,7 +730,10 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     if (ctx->knobs.vis_bitmap) tab_fit = 0;
     // Narrow batches (the reference's call pattern is ONE query per Hnsw::search): a four-wave workgroup per query,
     // one workgroup per CU — the rows of an expansion are fetched by all four SIMDs in one round trip.
-    const uint32_t quad_nq = ctx->knobs.quad_nq == 0xFFFFFFFFu ? (uint32_t)ix->n_cu : ctx->knobs.quad_nq;
+    // Two such workgroups share a CU where the kernel's registers allow it (all but the 768-d instantiation): up to two
+    // queries per CU the four-wave walk beats the single-wave one (512 queries: 0.65 vs 0.81 ms at C3), beyond it loses.
+    const uint32_t quad_per_cu = (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0) ? 1u : 2u;
+    const uint32_t quad_nq = ctx->knobs.quad_nq == 0xFFFFFFFFu ? (uint32_t)ix->n_cu * quad_per_cu : ctx->knobs.quad_nq;
     const bool quad = tab_fit && !ctx->knobs.classic && nq <= quad_nq;
     const bool cache_resident = (size_t)ix->n * ix->L.stride * 4 <= kCacheResidentBytes;
     const bool wide_on_chip = tab_fit && (ctx->knobs.vis_onchip || ctx->knobs.tab_log2 ||
@@ -738,7 +741,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const bool on_chip = quad || wide_on_chip;
     const uint32_t tab_log2 = on_chip ? tab_fit : 0u;
     a.tab_log2 = tab_log2;
-    const uint32_t resident = (uint32_t)ix->n_cu * (quad ? 1u : (on_chip ? 4u : 16u));
+    const uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (on_chip ? 4u : 16u));   // quad: two workgroups per CU where registers allow
     CHK(ensure_slots(ctx, std::min(nq, resident), stream));
     ctx->last_ef = ef;
     a.out_pid = d_pid;

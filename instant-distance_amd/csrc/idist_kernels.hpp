@@ -148,8 +148,9 @@ __device__ __forceinline__ void visited_attach_tab(Visited& v, uint32_t* mem, ui
 // LAT: walk mode (kWalkClassic / kWalkLatency / kWalkOverlap, see search_layer).
 // waves per SIMD a walk code asks the register allocator for (0 = its own choice)
 #ifndef IDIST_WAVES_ATTR
+// (the four-wave walk may share a SIMD with a second workgroup's wave: batches between one and two queries per CU)
 #define IDIST_WAVES_ATTR(LAT_) \
-    __attribute__((amdgpu_waves_per_eu(walk_waves(LAT_) ? walk_waves(LAT_) : 1, walk_waves(LAT_) ? walk_waves(LAT_) : 8)))
+    __attribute__((amdgpu_waves_per_eu(walk_waves(LAT_) ? walk_waves(LAT_) : 1, walk_quad(LAT_) ? 2 : (walk_waves(LAT_) ? walk_waves(LAT_) : 8))))
 #endif
 // Walk codes with the quad bit run four-wave workgroups (256 threads): wave 0 is the walk below, waves 1-3 only
 // take their share of every distance pass (QuadCtl, idist_device.hpp).
