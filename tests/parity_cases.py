@@ -27,6 +27,7 @@ SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by
 # The descent of an insertion shares the walk code; what varies there is the walk mode (classic / overlap) and the size
 # of the on-chip visited set — it never runs four waves per item and has no bitmap-only variant.
 BUILD_VARIANTS = (("on-chip", {}),
+                  ("step A2 with the LDS-tile kernel instead of the Gram matrix on MFMA", {"IDIST_BUILD_A2": "tile"}),
                   ("on-chip classic", {"IDIST_WALK": "classic"}),
                   ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7"}),
                   ("on-chip, set of 32 ids: bitmap from the start", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}))
@@ -36,7 +37,7 @@ BUILD_VARIANTS = (("on-chip", {}),
 def search_variant(env):
     if isinstance(env, str):                     # a bare IDIST_LATENCY_NQ value
         env = {"IDIST_LATENCY_NQ": env}
-    keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ")
+    keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ", "IDIST_BUILD_A2")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)
