@@ -374,7 +374,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
     uint32_t* d_small = nullptr;           // [0] n_touched, [1..5] queue (A, B, n_slow, B2, A2), [6] status
     uint64_t *d_wbuf = nullptr, *d_dlog_log = nullptr;
-    uint32_t *d_dlog_pid = nullptr, *d_dlog_dist = nullptr;
+    uint32_t* d_dlog_pd = nullptr;
     uint32_t* d_wcount = nullptr;
     uint32_t *d_row_nsel = nullptr, *d_slow = nullptr, *d_nbr_aux = nullptr;
     unsigned long long* d_stats = nullptr; // [8]
@@ -400,7 +400,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         if (s1) hipStreamDestroy(s1);
         if (s2) hipStreamDestroy(s2);
         for (int i = 0; i < 2; i++) { if (evA[i]) hipEventDestroy(evA[i]); if (evS[i]) hipEventDestroy(evS[i]); }
-        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount); hipFree(d_dlog_log); hipFree(d_dlog_pid); hipFree(d_dlog_dist);
+        hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount); hipFree(d_dlog_log); hipFree(d_dlog_pd);
         hipFree(d_vis); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
         if (e0) hipEventDestroy(e0);
@@ -429,8 +429,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     BCHK(hipMalloc((void**)&d_wcount, np * cap * 4));
     const size_t dl_n = cfg.has_heuristic ? (np * cap) << tab_log2 : 64;   // the simple splice looks nothing up
     BCHK(hipMalloc((void**)&d_dlog_log, dl_n * 8));
-    BCHK(hipMalloc((void**)&d_dlog_pid, dl_n * 4));
-    BCHK(hipMalloc((void**)&d_dlog_dist, dl_n * 4));
+    BCHK(hipMalloc((void**)&d_dlog_pd, dl_n * 8));
     if (pipe) {
         BCHK(hipMalloc((void**)&d_zero2, (size_t)n * IDIST_M2 * 4));
         BCHK(hipMemset(d_zero2, 0xFF, (size_t)n * IDIST_M2 * 4));
@@ -476,8 +475,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     a.n_slow = d_small + 3;      // == &queue[2]
     a.status = d_small + 6;
     a.dlog_log = d_dlog_log;
-    a.dlog_pid = d_dlog_pid;
-    a.dlog_dist = d_dlog_dist;
+    a.dlog_pd = d_dlog_pd;
     a.tab_log2 = tab_log2;
     a.use_dlog = getenv("IDIST_BUILD_NO_DLOG") ? 0u : 1u;
     a.wbuf = d_wbuf;
@@ -534,8 +532,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
                 viewS.zero = zbuf[par];
                 aA.queue = d_small + 1;
                 aA.dlog_log = d_dlog_log + (((size_t)par * cap) << tab_log2);
-                aA.dlog_pid = d_dlog_pid + (((size_t)par * cap) << tab_log2);
-                aA.dlog_dist = d_dlog_dist + (((size_t)par * cap) << tab_log2);
+                aA.dlog_pd = d_dlog_pd + (((size_t)par * cap) << (tab_log2 + 1u));
                 aA.wbuf = d_wbuf + (size_t)par * cap * cfg.ef_construction;
                 aA.wcount = d_wcount + (size_t)par * cap;
                 BCHK(hipMemsetAsync(d_small, 0, 8, sA));                  // step A queue head

@@ -564,27 +564,29 @@ __device__ __forceinline__ int bucket_find(const uint4 e, uint32_t pid) {
 __device__ __forceinline__ int bucket_fill(const uint4 e) {      // entries in use = index of the first empty one
     return e.x == kInvalid ? 0 : (e.y == kInvalid ? 1 : (e.z == kInvalid ? 2 : (e.w == kInvalid ? 3 : 4)));
 }
-// index of pid in a set stored at T (bmask + 1 buckets, hashes shifted by bshift), -1 if it is not there
+// index (in words) of pid in a set stored at T (bmask + 1 buckets of BW words — the four ids first —, hashes shifted by
+// bshift), -1 if it is not there.  BW = 4: the on-chip set; BW = 8: the published form, ids + their four distances
+template <uint32_t BW>
 __device__ __forceinline__ int tabset_index(const uint32_t* T, uint32_t bmask, uint32_t bshift, uint32_t pid) {
     const uint32_t b1 = tab_hash1(pid, bshift), b2 = tab_hash2(pid, bshift);
-    const uint4 e1 = *reinterpret_cast<const uint4*>(T + 4u * b1);
-    const uint4 e2 = *reinterpret_cast<const uint4*>(T + 4u * b2);
+    const uint4 e1 = *reinterpret_cast<const uint4*>(T + BW * b1);
+    const uint4 e2 = *reinterpret_cast<const uint4*>(T + BW * b2);
     int k = bucket_find(e1, pid);
-    if (k >= 0) return (int)(4u * b1) + k;
+    if (k >= 0) return (int)(BW * b1) + k;
     k = bucket_find(e2, pid);
-    if (k >= 0) return (int)(4u * b2) + k;
+    if (k >= 0) return (int)(BW * b2) + k;
     if (e1.w == kInvalid || e2.w == kInvalid) return -1;       // a home bucket has room: the id never overflowed
     uint32_t b = (b2 + 1u) & bmask;
     for (uint32_t probe = 0; probe <= bmask; probe++) {
-        const uint4 e = *reinterpret_cast<const uint4*>(T + 4u * b);
+        const uint4 e = *reinterpret_cast<const uint4*>(T + BW * b);
         k = bucket_find(e, pid);
-        if (k >= 0) return (int)(4u * b) + k;
+        if (k >= 0) return (int)(BW * b) + k;
         if (e.w == kInvalid) return -1;
         b = (b + 1u) & bmask;
     }
     return -1;
 }
-__device__ __forceinline__ int tab_index(const Visited& v, uint32_t pid) { return tabset_index(v.tab, v.tmask, v.tshift, pid); }
+__device__ __forceinline__ int tab_index(const Visited& v, uint32_t pid) { return tabset_index<4>(v.tab, v.tmask, v.tshift, pid); }
 __device__ __forceinline__ bool tab_find(const Visited& v, uint32_t pid) { return tab_index(v, pid) >= 0; }
 // insert pid into the LDS set: its index if it was new, -1 if it was there already.  The set is never full
 // (frozen at 7/8, visited_begin), so the overflow walk ends.
@@ -715,16 +717,17 @@ __device__ __forceinline__ void dlog_append(DistLog& L, int idx, uint32_t dist_b
     if (idx >= 0) L.log[L.n + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = ((uint64_t)dist_bits << 32) | (uint32_t)idx;
     L.n += (uint32_t)__popcll(m);
 }
-// End of the descent: ids of the set -> out_pid (all entries, empty ones included: nothing to clear beforehand);
-// then the set's LDS is reused to sort the logged distances by index, and that array goes out in one coalesced
-// pass too (entries of empty slots are never read).  HBM sees full-sector streaming writes only.  The on-chip set
-// is destroyed: the caller clears it (visited_clear) before the next descent.
-__device__ __forceinline__ void dlog_publish(const DistLog& L, const Visited& v, uint32_t* out_pid, uint32_t* out_dist) {
+// End of the descent: the set goes out in its published form, one 32-B record per bucket = its four ids followed by
+// their four distances, so that a lookup of step B touches one sector per home bucket and finds the distance in the
+// same one.  First the ids (all buckets, empty entries included: nothing to clear beforehand); then the set's LDS is
+// reused to sort the logged distances by index, and they go out into the other half of every record (entries of
+// empty slots are never read).  The on-chip set is destroyed: the caller clears it (visited_clear) before the next descent.
+__device__ __forceinline__ void dlog_publish(const DistLog& L, const Visited& v, uint32_t* out_pd) {
     const int lane = lane_id();
     wave_sync();
     uint4* t = reinterpret_cast<uint4*>(v.tab);
-    uint4* o = reinterpret_cast<uint4*>(out_pid);
-    for (uint32_t i = lane; i <= v.tmask; i += 64) o[i] = t[i];
+    uint4* o = reinterpret_cast<uint4*>(out_pd);
+    for (uint32_t i = lane; i <= v.tmask; i += 64) o[2u * i] = t[i];
     visited_drain();                                       // the log's own stores have landed before it is read back
     wave_sync();
     constexpr int kDeep = 16;                              // log entries per lane in flight: one round trip per 1024 entries
@@ -740,13 +743,12 @@ __device__ __forceinline__ void dlog_publish(const DistLog& L, const Visited& v,
             if (base + 64u * (uint32_t)u + (uint32_t)lane < L.n) v.tab[(uint32_t)e[u]] = (uint32_t)(e[u] >> 32);
     }
     wave_sync();
-    o = reinterpret_cast<uint4*>(out_dist);
-    for (uint32_t i = lane; i <= v.tmask; i += 64) o[i] = t[i];
+    for (uint32_t i = lane; i <= v.tmask; i += 64) o[2u * i + 1u] = t[i];
 }
 // step B: d(new, pid) from the published set of `new`'s descent, kDlogMiss if it is not there
-__device__ __forceinline__ uint32_t dlog_find(const uint32_t* P, const uint32_t* D, uint32_t bmask, uint32_t bshift, uint32_t pid) {
-    const int i = tabset_index(P, bmask, bshift, pid);
-    return i >= 0 ? D[i] : kDlogMiss;
+__device__ __forceinline__ uint32_t dlog_find(const uint32_t* PD, uint32_t bmask, uint32_t bshift, uint32_t pid) {
+    const int i = tabset_index<8>(PD, bmask, bshift, pid);
+    return i >= 0 ? PD[i + 4] : kDlogMiss;
 }
 
 struct Counters {

@@ -358,8 +358,7 @@ struct BuildArgs {
     uint32_t* n_slow;
     // distance log of every new point's descent (DistLog): append log, then the published set ids / distances
     uint64_t* dlog_log;         // [max_batch][1 << tab_log2]
-    uint32_t* dlog_pid;         // [max_batch][1 << tab_log2]
-    uint32_t* dlog_dist;        // [max_batch][1 << tab_log2]
+    uint32_t* dlog_pd;          // [max_batch][2 << tab_log2] published sets: per bucket four ids + their four distances
     uint32_t tab_log2;          // log2(ids) of the descent's on-chip visited set
     uint32_t use_dlog;          // 0: nothing is logged, step B computes every distance it needs (IDIST_BUILD_NO_DLOG, test / A-B knob)
     uint64_t* wbuf;             // [max_batch][efc] Search.nearest of every new point (step A -> step A2)
@@ -472,7 +471,7 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
             // select_heuristic (:470-472) runs in step A2 with the selected rows on chip; hand Search.nearest over
             for (int i = lane; i < nw; i += 64) a.wbuf[(size_t)item * a.efc + i] = st.W[i] & kKeyMask;
             if (lane == 0) a.wcount[item] = (uint32_t)nw;
-            if (dl.log) dlog_publish(dl, vis, a.dlog_pid + ((size_t)item << a.tab_log2), a.dlog_dist + ((size_t)item << a.tab_log2));
+            if (dl.log) dlog_publish(dl, vis, a.dlog_pd + ((size_t)item << (a.tab_log2 + 1u)));
         } else {                                                      // select_simple, :466-469, :758-760
             const int nsel = nw < kM2 ? nw : kM2;
             if (lane < nsel) sel[lane] = st.W[lane] & kKeyMask;
@@ -935,11 +934,10 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             const uint32_t new_pid = (uint32_t)knew, cd_new = (uint32_t)(knew >> 32);
             const bool selL = lane < ns0, discL = lane >= ns0 && lane < ncur;
             const uint64_t below = (1ull << lane) - 1ull;
-            const uint32_t* TP = a.dlog_pid + ((size_t)(new_pid - a.start) << a.tab_log2);
-            const uint32_t* TD = a.dlog_dist + ((size_t)(new_pid - a.start) << a.tab_log2);
+            const uint32_t* TPD = a.dlog_pd + ((size_t)(new_pid - a.start) << (a.tab_log2 + 1u));
             const uint32_t bmask = (1u << (a.tab_log2 - 2u)) - 1u, bshift = 32u - (a.tab_log2 - 2u);
             uint32_t dn = kDlogMiss;                         // d(new, selected entry of this lane)
-            if (selL && a.use_dlog) dn = dlog_find(TP, TD, bmask, bshift, cur);
+            if (selL && a.use_dlog) dn = dlog_find(TPD, bmask, bshift, cur);
             const bool miss = selL && dn == kDlogMiss;
             const uint64_t mm = __ballot(miss);
             if (mm) {
@@ -1034,11 +1032,10 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             const int nx = ns0 + k_new;
             for (int ai = 0; ai < k_new; ai++) {
                 const uint32_t a_pid = (uint32_t)news[ai];
-                const uint32_t* TP = a.dlog_pid + ((size_t)(a_pid - a.start) << a.tab_log2);
-                const uint32_t* TD = a.dlog_dist + ((size_t)(a_pid - a.start) << a.tab_log2);
+                const uint32_t* TPD = a.dlog_pd + ((size_t)(a_pid - a.start) << (a.tab_log2 + 1u));
                 const uint32_t bmask = (1u << (a.tab_log2 - 2u)) - 1u, bshift = 32u - (a.tab_log2 - 2u);
                 uint32_t dv = kDlogMiss;
-                if (lane < ns0 && a.use_dlog) dv = dlog_find(TP, TD, bmask, bshift, X[lane]);
+                if (lane < ns0 && a.use_dlog) dv = dlog_find(TPD, bmask, bshift, X[lane]);
                 if (lane < ns0) Dn[ai * kFastX + lane] = dv;
                 int nmiss = 0;
                 // columns [0, ns0) that missed + the other new points: gather those rows
