@@ -169,6 +169,7 @@ struct Knobs {
     uint32_t tab_log2 = 0;        // IDIST_TAB_LOG2=<5..13>: size of the on-chip visited set (test knob: small sets exercise the overflow path)
     bool vis_bitmap = false;      // IDIST_VISITED=bitmap: search with bitmap + Bloom filter (16 waves per CU) instead of the on-chip set
     bool vis_onchip = false;      // IDIST_VISITED=onchip: the on-chip set whatever the policy says (test / A-B knob)
+    bool no_zero_copy = false;    // IDIST_NO_ZERO_COPY=1: narrow host-pointer batches take the general (staged) path too (test / A-B knob)
     int tune = -1;                // IDIST_TUNE=<i> (tuning builds only, -DIDIST_TUNE): i-th experimental walk variant
     uint32_t quad_nq = 0xFFFFFFFFu;   // IDIST_QUAD_NQ: batches up to this many queries run four waves per query (default: two
                                       // workgroups per CU, one for 768-d rows; 0 = never)
@@ -180,6 +181,7 @@ struct Knobs {
         if (const char* e = getenv("IDIST_WALK")) k.classic = e[0] == 'c';
         if (const char* e = getenv("IDIST_BLOOM")) k.bloom = e[0] != '0';
         if (const char* e = getenv("IDIST_VISITED")) { k.vis_bitmap = e[0] == 'b'; k.vis_onchip = e[0] == 'o'; }
+        if (const char* e = getenv("IDIST_NO_ZERO_COPY")) k.no_zero_copy = e[0] != '0';
         if (const char* e = getenv("IDIST_TAB_LOG2")) k.tab_log2 = std::min(13u, std::max(5u, (uint32_t)atoi(e)));
         return k;
     }
@@ -193,6 +195,13 @@ struct idist_search_ctx {
     VisGeom vis{};
     uint32_t* d_visited = nullptr; // [slots][vis.slot_words], all-zero between launches
     uint32_t* d_next = nullptr;    // [0] queue head, [1] status
+    uint32_t queue_base = 0;       // value of the queue head before the next launch (it is never reset: each launch of nq queries on
+                                   // g workgroups moves it by nq + g, unsigned wrap-around included)
+    // narrow host-pointer batches (the reference's one query per call): query and results cross PCIe through one pinned,
+    // device-mapped buffer the kernel reads and writes directly — no memcpy / memset calls around the launch
+    uint8_t* h_io = nullptr;       // host address
+    uint8_t* d_io = nullptr;       // the same memory as the device sees it
+    static constexpr size_t kIoBytes = 64 * 1024, kIoStatusSlots = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev0[IDIST_EVENT_RING] = {nullptr}, ev1[IDIST_EVENT_RING] = {nullptr};
     uint64_t n_launch = 0;
@@ -708,7 +717,8 @@ inline uint32_t on_chip_max_ef(uint32_t stride_floats) { return std::min(1536u, 
 constexpr size_t kCacheResidentBytes = (size_t)128 << 20;
 
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
-                           uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream) {
+                           uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream,
+                           uint32_t* status_host = nullptr, uint32_t* grid_out = nullptr) {
     const uint32_t ef = ix->cfg.ef_search;
     SearchArgs a{};
     a.queries = d_q;
@@ -758,7 +768,9 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const uint32_t grid = std::min(std::min(nq, ctx->slots), resident);
     const bool classic = ctx->knobs.classic;
     IndexView view = ix->view();
-    HIPCHK(hipMemsetAsync(ctx->d_next, 0, 4, stream));
+    a.queue_base = ctx->queue_base;
+    a.status_host = status_host && grid <= idist_search_ctx::kIoStatusSlots ? status_host : nullptr;
+    if (grid_out) *grid_out = grid;
     const uint32_t slot = (uint32_t)(ctx->n_launch % IDIST_EVENT_RING);
     HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
 #define LAUNCH_SEARCH(NB_, RS_, TAIL_)                                                             \
@@ -810,7 +822,13 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
 #endif
     IDIST_DISPATCH(ix->L, LAUNCH_SEARCH);
 #undef LAUNCH_SEARCH
-    HIPCHK(hipGetLastError());
+    if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
+        // nothing ran: put the queue head back where a fresh context has it
+        hipMemsetAsync(ctx->d_next, 0, 4, stream);
+        ctx->queue_base = 0;
+        return fail(IDIST_ERR_HIP, "search launch failed: %s", hipGetErrorString(le));
+    }
+    ctx->queue_base += nq + grid;
     HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
     ctx->n_launch++;
     return IDIST_OK;
@@ -1115,6 +1133,7 @@ void idist_search_ctx_free(idist_search_ctx* c) {
     // (the index may already be gone: nothing of it is touched here)
     hipFree(c->d_visited);
     hipFree(c->d_next);
+    if (c->h_io) hipHostFree(c->h_io);
     hipFree(c->d_q);
     hipFree(c->d_pid);
     hipFree(c->d_dist);
@@ -1206,6 +1225,47 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
     if (!out_pid || !out_dist) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
     HIPCHK(hipSetDevice(idx->device));
     const size_t qb = (size_t)nq * idx->dim * 4, ob = (size_t)nq * ef * 4;
+    // Narrow batches — the reference's call is ONE query per Hnsw::search: query and results cross PCIe through one
+    // pinned, device-mapped buffer that the kernel reads and writes itself; the call is a host memcpy, one launch, one
+    // stream sync, a host memcpy.  (The general path below costs six copy / memset calls of ~10 us each around the kernel.)
+    const size_t io_need = qb + 2 * ob + (size_t)nq * 16 + idist_search_ctx::kIoStatusSlots * 4;
+    if (io_need <= idist_search_ctx::kIoBytes && !ctx->knobs.no_zero_copy) {
+        if (!ctx->h_io) {
+            HIPCHK(hipHostMalloc((void**)&ctx->h_io, idist_search_ctx::kIoBytes, hipHostMallocPortable | hipHostMallocMapped));
+            if (hipHostGetDevicePointer((void**)&ctx->d_io, ctx->h_io, 0) != hipSuccess) ctx->d_io = ctx->h_io;
+        }
+        uint8_t* hp = ctx->h_io;
+        uint32_t* h_status = (uint32_t*)hp;                                   // [256]
+        float* h_q = (float*)(hp + idist_search_ctx::kIoStatusSlots * 4);
+        uint32_t* h_pid = (uint32_t*)((uint8_t*)h_q + qb);
+        float* h_dist = (float*)((uint8_t*)h_pid + ob);
+        uint32_t* h_cnt = (uint32_t*)((uint8_t*)h_dist + ob);
+        uint32_t* h_ctr = h_cnt + nq;
+        const ptrdiff_t dv = ctx->d_io - ctx->h_io;                           // host address -> device address of the same byte
+        for (;;) {
+            memcpy(h_q, queries, qb);
+            memset(h_status, 0, idist_search_ctx::kIoStatusSlots * 4);
+            uint32_t grid = 0;
+            CHK(launch_search(idx, ctx, (const float*)((uint8_t*)h_q + dv), nq, (uint32_t*)((uint8_t*)h_pid + dv),
+                              (float*)((uint8_t*)h_dist + dv), (uint32_t*)((uint8_t*)h_cnt + dv),
+                              out_counters ? (uint32_t*)((uint8_t*)h_ctr + dv) : nullptr, ctx->stream,
+                              (uint32_t*)((uint8_t*)h_status + dv), &grid));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            uint32_t any = grid <= idist_search_ctx::kIoStatusSlots ? 0u : 1u;  // too many workgroups for the slots: ask the device
+            for (uint32_t g = 0; g < grid && g < idist_search_ctx::kIoStatusSlots; g++) any |= h_status[g];
+            if (any) {
+                const uint32_t cap_before = std::max(tie_capacity(idx->cfg), ctx->tie_cap);
+                const idist_status s = idist_search_ctx_status(ctx);
+                if (s == IDIST_ERR_TIE_OVERFLOW && std::max(tie_capacity(idx->cfg), ctx->tie_cap) > cap_before) continue;
+                if (s != IDIST_OK) return s;
+            }
+            memcpy(out_pid, h_pid, ob);
+            memcpy(out_dist, h_dist, ob);
+            memcpy(out_count, h_cnt, (size_t)nq * 4);
+            if (out_counters) memcpy(out_counters, h_ctr, (size_t)nq * 12);
+            return IDIST_OK;
+        }
+    }
     if (qb > ctx->cap_q) { hipFree(ctx->d_q); ctx->d_q = nullptr; ctx->cap_q = 0; HIPCHK(hipMalloc((void**)&ctx->d_q, qb)); ctx->cap_q = qb; }
     if (ob > ctx->cap_out) {
         hipFree(ctx->d_pid); hipFree(ctx->d_dist); ctx->d_pid = nullptr; ctx->d_dist = nullptr; ctx->cap_out = 0;

@@ -130,8 +130,11 @@ struct SearchArgs {
     uint32_t* out_counters; // [nq][3] or null
     uint32_t* visited;      // [slots][vis.slot_words] bitmaps, all-zero between launches
     VisGeom vis;            // vis_geometry(n)
-    uint32_t* next;         // work queue head
+    uint32_t* next;         // work queue head: counts on from launch to launch (no reset between launches), see queue_base
+    uint32_t queue_base;    // value of *next when this launch starts: every launch adds nq + gridDim.x (one failed dequeue per workgroup)
     uint32_t* status;
+    uint32_t* status_host;  // [gridDim.x] in pinned host memory or null: per-workgroup copy of a non-zero status (host-pointer calls
+                            // of narrow batches read it after the stream sync instead of copying the device word back)
     uint32_t use_bloom;     // LDS Bloom filter in front of the visited bitmap (walks without the on-chip set)
     uint32_t tab_log2;      // log2(entries) of the on-chip visited set (walks with it)
     uint32_t tie_cap;       // capacity of the tie region (idist_config.tie_capacity)
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
     visited_clear(vis);                                                // LDS side; the slot's bitmap is clean between launches
     for (;;) {
         uint32_t qi = 0;
-        if (lane == 0) qi = atomicAdd(a.next, 1u);
+        if (lane == 0) qi = atomicAdd(a.next, 1u) - a.queue_base;
         qi = uniform_u32(qi);
         if (qi >= a.nq) break;
 
@@ -238,7 +241,10 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         visited_clear(vis);                                            // leave the slot empty for its next search
     }
     if constexpr (walk_quad(LAT)) quad_release_helpers(sm.ctl);
-    if (lane == 0 && status) atomicOr(a.status, status);
+    if (lane == 0 && status) {
+        atomicOr(a.status, status);
+        if (a.status_host) a.status_host[blockIdx.x] = status;
+    }
 }
 
 // ---------------------------------------------------------------------------
