@@ -231,8 +231,11 @@ __global__ __launch_bounds__(64) void rerank_kernel(IndexView ix, const float* _
 //
 // The order-defining comparison is `d(c_i, c_j) < d(c_i, q)` (:676-679) with the CANONICAL distance; a product-form
 // distance |c_i|^2 + |c_j|^2 - 2 c_i.c_j rounds differently, so it is used as a filter with a margin, never as the
-// answer: with G~ from v_mfma_f32_32x32x2_f32 and eps_ij = kGramEps * K * (|c_i|^2 + |c_j|^2) (K = stored row length; the
-// f32 error of either form is below K * 2^-24 of that scale),
+// answer: with G~ from v_mfma_f32_32x32x2_f32 and eps_ij = kGramEps * K * (|c_i|^2 + |c_j|^2) (K = stored row length).
+// Error budget: a K-term fma chain is off by at most ~K u sum|a_k b_k| <= K u |a||b| (u = 2^-24), so the three chains of G~
+// are within 2 K u (|c_i|^2 + |c_j|^2) of the true value, the canonical 8-chain sum within (K/8 + 3) u d <= 0.3 K u (...)
+// of it: |G~ - canonical| <= 2.3 K u (|c_i|^2 + |c_j|^2), and eps is 4 K u (...) plus an absolute floor of 1e-30 for
+// inputs so small that a flushed denormal could matter.  With it,
 //      G~ + eps <  d(c_i,q)   =>  c_j is closer for certain          (bit in closer[i])
 //      G~ - eps >= d(c_i,q)   =>  it is not, for certain
 //      otherwise              =>  uncertain: the canonical distance is computed for that pair (bit in unsure[i]).
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256) IDIST_A2M_ATTR void build_select_mfma_kernel(I
                     const int i = kTi[t] * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const float ni = norms[i], cd = cdf[i];
                     const float g = ni + nj - 2.0f * acc[t][r];
-                    const float eps = eps_k * (ni + nj);
+                    const float eps = eps_k * (ni + nj) + 1e-30f;         // + a floor far above any flushed-denormal product sum
                     const bool valid = j < i && i < nw;
                     const bool cl = valid && (g + eps < cd);
                     const bool ncl = g - eps >= cd;
