@@ -111,6 +111,9 @@ def test_search_on_parallel_built_graph(eng, oracle):
     (1, 4, {}), (2, 4, {}), (5, 2, {"metric": 1}), (33, 3, {}), (100, 2, {"metric": 1}),
     (150, 12, {}), (120, 300, {}), (140, 8, {"ef_construction": 20}), (130, 5, {"keep_pruned": False}),
     (140, 3, {"kind": "grid", "metric": 1}),
+    # squared-L2 grids: exact ties d(c_i, c_j) == d(c_i, q) all over — the MFMA selection filter must send them to the
+    # canonical distance and keep the strict `<` of core/lib.rs:678
+    (140, 3, {"kind": "grid"}), (160, 2, {"kind": "grid", "ef_construction": 40}),
     (150, 6, {"heuristic": False}), (120, 2, {"heuristic": False, "metric": 1}), (100, 300, {"heuristic": False}),
     (130, 3, {"heuristic": False, "kind": "grid", "metric": 1}),
 ])
@@ -139,6 +142,16 @@ def test_build_exact_extend_candidates(eng, oracle, n, dim, kw):
 def test_build_exact_gpu(engine_loader, oracle, n, dim, heur):
     ida = engine_loader("gpu")
     pc.check_build_exact(ida, oracle, n=n, dim=dim, seed=n, heuristic=heur)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dim,efc", [(3000, 4, 60), (2500, 6, 100)])
+def test_build_exact_gpu_squared_l2_lattice(engine_loader, oracle, n, dim, efc):
+    """Integer lattices under squared L2: every selection is full of exact ties d(c_i, c_j) == d(c_i, q).  The Gram-matrix
+    filter on the matrix cores (build_select_mfma_kernel) may decide none of them: they must all reach the canonical
+    distance with the strict `<` of core/lib.rs:678, or the graph differs from the oracle's."""
+    ida = engine_loader("gpu")
+    pc.check_build_exact(ida, oracle, n=n, dim=dim, seed=n, kind="grid", ef_construction=efc)
 
 
 @pytest.mark.gpu
