@@ -1393,57 +1393,6 @@ idist_status idist_search_batch_sharded(const idist_index* const* replicas, idis
     return IDIST_OK;
 }
 
-#ifdef IDIST_TUNE
-// tuning build only (libidist_tune.so; not part of the ABI): place a context's visited bitmaps / an index's point rows
-// at a caller-chosen device address (placement studies).  The previous buffer is NOT freed; the caller owns `ptr`.
-extern "C" idist_status idist_tune_set_visited(idist_search_ctx* ctx, void* ptr, uint32_t slots) {
-    if (hipDeviceSynchronize() != hipSuccess) return IDIST_ERR_HIP;
-    if (hipMemset(ptr, 0, (size_t)slots * ctx->vis.slot_words * 4) != hipSuccess) return IDIST_ERR_HIP;
-    ctx->d_visited = (uint32_t*)ptr;
-    ctx->slots = slots;
-    ctx->slots_req = slots;
-    return IDIST_OK;
-}
-// which: 0 = point rows, 1 = zero layer, 2 = upper layers.  `src` = where a pristine copy lives (never overlapping ptr).
-extern "C" idist_status idist_tune_move_buffer(idist_index* idx, int which, void* ptr, const void* src) {
-    if (hipDeviceSynchronize() != hipSuccess) return IDIST_ERR_HIP;
-    const size_t bytes = which == 0 ? (size_t)idx->n * idx->L.stride * 4 : which == 1 ? (size_t)idx->n * IDIST_M2 * 4 : idx->upper_rows * IDIST_M * 4;
-    if (hipMemcpy(ptr, src, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return IDIST_ERR_HIP;
-    if (which == 0) idx->d_points = (float*)ptr; else if (which == 1) idx->d_zero = (uint32_t*)ptr; else idx->d_upper = (uint32_t*)ptr;
-    return hipDeviceSynchronize() == hipSuccess ? IDIST_OK : IDIST_ERR_HIP;
-}
-// kernel time (ms, HIP events, best of reps) of the stand-alone gather-L2 kernel over n_ids pseudo-random rows per query
-extern "C" idist_status idist_tune_gather_ms(const idist_index* idx, uint32_t nq, uint32_t n_ids, int reps, float* ms_out) {
-    float* d_q = nullptr; float* d_out = nullptr; uint32_t* d_ids = nullptr;
-    std::vector<uint32_t> ids((size_t)nq * n_ids);
-    uint64_t x = 88172645463325252ull;
-    for (auto& v : ids) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (uint32_t)(x % idx->n); }
-    if (hipMalloc((void**)&d_q, (size_t)nq * idx->dim * 4) != hipSuccess || hipMalloc((void**)&d_out, ids.size() * 4) != hipSuccess ||
-        hipMalloc((void**)&d_ids, ids.size() * 4) != hipSuccess) return IDIST_ERR_HIP;
-    hipMemset(d_q, 0, (size_t)nq * idx->dim * 4);
-    hipMemcpy(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice);
-    const uint32_t chunks = (n_ids + 63u) / 64u;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)nq * chunks, 256u * 16u);
-    const size_t smem = smem_bytes(idx->L.stride, 0, false);
-    IndexView view = idx->view();
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    float best = 1e30f;
-    for (int r = 0; r < reps; r++) {
-        hipEventRecord(e0, nullptr);
-        auto kD = distance_batch_kernel<9, 1, 1>;
-        IDIST_LAUNCH(kD, grid, 64, smem, (hipStream_t) nullptr, view, d_q, nq, d_ids, n_ids, d_out);
-        hipEventRecord(e1, nullptr);
-        hipEventSynchronize(e1);
-        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-        best = std::min(best, ms);
-    }
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(d_q); hipFree(d_out); hipFree(d_ids);
-    *ms_out = best;
-    return IDIST_OK;
-}
-#endif
 
 idist_status idist_distance_batch(const idist_index* idx, const float* queries, uint32_t nq, const uint32_t* ids,
                                   uint32_t n_ids, float* out_dist) {

@@ -1,6 +1,6 @@
 // idist_device.hpp — wave64 device routines of the HNSW hot path for gfx950.
 //
-// One wavefront (= one 64-thread workgroup) owns one query / one insertion.
+// One wavefront owns one query / one insertion (narrow batches: a four-wave workgroup, its wave 0 is that wavefront).
 // Nothing here is a translation of the reference's data structures; the
 // reference semantics that must be reproduced bit-for-bit are cited inline
 // (paths relative to /root/reference/, core/ = instant-distance/src/).
@@ -12,10 +12,11 @@
 //                           pid, bit 63 = "already expanded".  The candidate
 //                           heap of core/lib.rs:564 is not materialised: the
 //                           live candidates are exactly the un-expanded entries
-//                           of that array (DESIGN.md §search-state proves the
-//                           equivalence, tests/test_wstate_model.py checks it).
-//   * visited             : one generation-stamped byte per point per slot in
-//                           HBM (core/types.rs:13-59), clear = generation += 1.
+//                           of that array (DESIGN.md §3 proves the equivalence;
+//                           `push` works on it in registers, w_push_merge).
+//   * visited             : exact set membership (core/types.rs:13-59): a
+//                           two-bucket hash set of ids in LDS per walk; what it
+//                           cannot hold goes to one bit per point and slot in HBM.
 #pragma once
 #ifdef IDIST_EMU
 #include "hip_emu.hpp"   // tests/simt: CPU lockstep emulation of one wave (test infrastructure)
