@@ -201,7 +201,8 @@ struct idist_search_ctx {
     // device-mapped buffer the kernel reads and writes directly — no memcpy / memset calls around the launch
     uint8_t* h_io = nullptr;       // host address
     uint8_t* d_io = nullptr;       // the same memory as the device sees it
-    static constexpr size_t kIoBytes = 64 * 1024, kIoStatusSlots = 256;
+    size_t io_cap = 0;             // bytes of that buffer: 64 KB on first use, grown on demand up to kIoMaxBytes
+    static constexpr size_t kIoMinBytes = 64 * 1024, kIoMaxBytes = 256 * 1024, kIoStatusSlots = 256;   // ~100 queries: beyond that the staged copies are as fast (profiles/probe_r02_quad_single_query_phases.jsonl)
     hipStream_t stream = nullptr;
     hipEvent_t ev0[IDIST_EVENT_RING] = {nullptr}, ev1[IDIST_EVENT_RING] = {nullptr};
     uint64_t n_launch = 0;
@@ -1229,10 +1230,17 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
     // pinned, device-mapped buffer that the kernel reads and writes itself; the call is a host memcpy, one launch, one
     // stream sync, a host memcpy.  (The general path below costs six copy / memset calls of ~10 us each around the kernel.)
     const size_t io_need = qb + 2 * ob + (size_t)nq * 16 + idist_search_ctx::kIoStatusSlots * 4;
-    if (io_need <= idist_search_ctx::kIoBytes && !ctx->knobs.no_zero_copy) {
-        if (!ctx->h_io) {
-            HIPCHK(hipHostMalloc((void**)&ctx->h_io, idist_search_ctx::kIoBytes, hipHostMallocPortable | hipHostMallocMapped));
+    if (io_need <= idist_search_ctx::kIoMaxBytes && !ctx->knobs.no_zero_copy) {
+        if (io_need > ctx->io_cap) {
+            size_t cap = idist_search_ctx::kIoMinBytes;
+            while (cap < io_need) cap <<= 1;
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (ctx->h_io) hipHostFree(ctx->h_io);
+            ctx->h_io = nullptr;
+            ctx->io_cap = 0;
+            HIPCHK(hipHostMalloc((void**)&ctx->h_io, cap, hipHostMallocPortable | hipHostMallocMapped));
             if (hipHostGetDevicePointer((void**)&ctx->d_io, ctx->h_io, 0) != hipSuccess) ctx->d_io = ctx->h_io;
+            ctx->io_cap = cap;
         }
         uint8_t* hp = ctx->h_io;
         uint32_t* h_status = (uint32_t*)hp;                                   // [256]

@@ -26,7 +26,7 @@ for nm, env in (("staged copies", {"IDIST_NO_ZERO_COPY": "1"}), ("zero-copy", {}
     os.environ.update(env)
     s = ida.Search()
     h.search_batch(q[:1], s)
-    for width in (1, 8):
+    for width in (1, 8, 64, 256, 512):
         t0 = time.perf_counter()
         res = [h.search_batch(q[i:i + width], s, counters=True) for i in range(0, 512, width)]
         wall = (time.perf_counter() - t0) / (512 / width) * 1e3
