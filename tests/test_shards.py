@@ -117,3 +117,29 @@ def test_search_scratch_grows_on_demand(eng, oracle):
     for slots in (1, 2, 5):                                           # fixed slot counts: fewer slots than queries
         got = h.search_batch(q, ida.Search(slots), counters=True)
         pc.check_search_result(got, want)
+
+
+def test_narrow_host_batches_zero_copy_equals_staged(eng, oracle, monkeypatch):
+    """Host-pointer batches of up to ~100 queries cross PCIe through the context's pinned, device-mapped buffer (the kernel
+    reads the queries and writes the results itself, the work-queue head runs on from launch to launch); wider ones and
+    IDIST_NO_ZERO_COPY=1 take the staged copies.  Same results either way, call after call on one context, and == oracle."""
+    ida, kind = eng
+    rng = np.random.default_rng(5)
+    n, dim = S(kind, 220, 6000), S(kind, 6, 48)
+    pts = rng.random((n, dim), dtype=np.float32)
+    oix = oracle.Index.build(pts, oracle.default_config(ef_search=30))
+    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().ef_search(30))
+    q = rng.random((S(kind, 9, 300), dim), dtype=np.float32)
+    want = oix.search(q)
+    for env in ({}, {"IDIST_NO_ZERO_COPY": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = ida.Search()
+        for width in (1, 2, 3, S(kind, 4, 150)):                       # the last width does not fit the zero-copy buffer on the GPU
+            for lo in range(0, len(q) - width + 1, width):
+                got = h.search_batch(q[lo:lo + width], s, counters=True)
+                assert np.array_equal(got.pid, want.pid[lo:lo + width]) and np.array_equal(got.count, want.count[lo:lo + width])
+                assert np.array_equal(got.distance.view(np.uint32), want.dist[lo:lo + width].view(np.uint32))
+                assert np.array_equal(got.counters, want.counters[lo:lo + width])
+        for k in env:
+            monkeypatch.delenv(k)
