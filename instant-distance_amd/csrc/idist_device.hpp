@@ -571,6 +571,10 @@ template <uint32_t BW>
 __device__ __forceinline__ int tabset_index(const uint32_t* T, uint32_t bmask, uint32_t bshift, uint32_t pid) {
     const uint32_t b1 = tab_hash1(pid, bshift), b2 = tab_hash2(pid, bshift);
     const uint4 e1 = *reinterpret_cast<const uint4*>(T + BW * b1);
+    if constexpr (BW == 8) {                                    // published form in HBM: the second home bucket only on a miss
+        const int k1 = bucket_find(e1, pid);
+        if (k1 >= 0) return (int)(BW * b1) + k1;
+    }
     const uint4 e2 = *reinterpret_cast<const uint4*>(T + BW * b2);
     int k = bucket_find(e1, pid);
     if (k >= 0) return (int)(BW * b1) + k;
