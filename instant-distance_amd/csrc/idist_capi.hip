@@ -372,7 +372,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
 
     uint64_t* d_ext_work = nullptr;
     uint32_t ext_cap = 1;
-    while (ext_cap < (cfg.ef_construction + 1u) * 65u + 64u) ext_cap <<= 1;       // a selection's working set, padded for the sort
+    // a selection's working set, padded for the sort: nearest (<= ef_construction for the new point, <= 65 = new + a full
+    // row for a neighbour's re-selection, whatever ef_construction is) plus up to 64 extensions per member
+    while (ext_cap < (std::max(cfg.ef_construction, 65u) + 1u) * 65u + 64u) ext_cap <<= 1;
     const size_t smemX = smem_bytes_extend(ix->L.stride, wcap, 1u << tab_log2, vg.dirty_words);
     if (ext && smemX > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave with extend_candidates (> 64 KiB)", smemX);
     // step A2 on the matrix cores (Gram matrix of the candidates as a filter, idist_mfma.hpp) where it applies
