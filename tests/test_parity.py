@@ -124,6 +124,7 @@ def test_build_exact_small(eng, oracle, n, dim, kw):
 
 @pytest.mark.parametrize("n,dim,kw", [
     (40, 3, {}), (70, 4, {"metric": 1}), (90, 5, {"keep_pruned": False}), (64, 300, {"ef_construction": 12}),
+    (130, 3, {"ef_construction": 8}),        # full rows, tiny ef_construction: a neighbour's working set (65 x 65) dwarfs the new point's
     (80, 2, {"kind": "grid", "metric": 1, "ef_construction": 20}),
 ])
 def test_build_exact_extend_candidates(eng, oracle, n, dim, kw):
