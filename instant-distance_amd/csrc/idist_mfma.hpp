@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void rerank_kernel(IndexView ix, const float* _
 //      G~ + eps <  d(c_i,q)   =>  c_j is closer for certain          (bit in closer[i])
 //      G~ - eps >= d(c_i,q)   =>  it is not, for certain
 //      otherwise              =>  uncertain: the canonical distance is computed for that pair (bit in unsure[i]).
-// The sequential part of the heuristic then is bit arithmetic on 128-bit masks; ~0.1 % of the pairs take the exact
+// The sequential part of the heuristic then is bit arithmetic on 128-bit masks; ~0.01 % of the pairs (C3 data) take the exact
 // path.  Results are identical to build_select_kernel's (same selected set, same order, a valid pruner per discarded
 // entry); tests run both (IDIST_BUILD_A2=tile selects the tile kernel).  Squared-L2 metric and ef_construction <= 128.
 //
