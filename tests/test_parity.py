@@ -113,7 +113,7 @@ def test_search_on_parallel_built_graph(eng, oracle):
     (140, 3, {"kind": "grid", "metric": 1}),
     # squared-L2 grids: exact ties d(c_i, c_j) == d(c_i, q) all over — the MFMA selection filter must send them to the
     # canonical distance and keep the strict `<` of core/lib.rs:678
-    (140, 3, {"kind": "grid"}), (160, 2, {"kind": "grid", "ef_construction": 40}),
+    (140, 3, {"kind": "grid"}), (110, 2, {"kind": "grid", "ef_construction": 40}),
     (150, 6, {"heuristic": False}), (120, 2, {"heuristic": False, "metric": 1}), (100, 300, {"heuristic": False}),
     (130, 3, {"heuristic": False, "kind": "grid", "metric": 1}),
 ])
