@@ -228,6 +228,10 @@ def test_build_batched_is_schedule_independent(eng, oracle, monkeypatch):
             {"IDIST_LATENCY_NQ": "0", "IDIST_WALK": "classic"}]
     if kind == "gpu":
         envs += [{"IDIST_BUILD_CHUNK": "1"}, {"IDIST_BUILD_CHUNK": "16"}, {"IDIST_LATENCY_NQ": "4000000000"}]
+    else:
+        # which kernel selects for the new points (Gram matrix on MFMA / LDS tile), whether step B finds its distances in
+        # the published log, how early the descents' visited set spills: none of it may show in the graph
+        envs += [{"IDIST_BUILD_A2": "tile"}, {"IDIST_BUILD_NO_DLOG": "1"}, {"IDIST_TAB_LOG2": "7"}]
     for env in envs:
         with monkeypatch.context() as m:
             m.setenv("IDIST_BUILD_CHECK", "1")
