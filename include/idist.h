@@ -211,7 +211,8 @@ void idist_index_free(idist_index* idx);
  * queries in flight.  The visited set is one BIT per point and slot (core/types.rs:13-59 keeps a byte and a
  * generation; membership is all that is observable).  slots = 0: like the reference's Search, which sizes its
  * scratch on first use (core/lib.rs:363), the context starts with ONE slot (n/8 bytes) and grows to what the
- * batches it is given need, at most a full chip (16 waves per CU = 4096 slots: 512 MB at 1M points).
+ * batches it is given need, at most a full chip (16 waves per CU = 4096 slots: 512 MB at 1M points; the default walk
+ * keeps the visited set of a query in LDS and touches this bitmap only when it overflows).
  * A context is bound to the index it was created for (by identity, not by address). */
 idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_search_ctx** out);
 void idist_search_ctx_free(idist_search_ctx* ctx);
@@ -225,7 +226,11 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx,
                                 const float* queries, uint32_t nq, uint32_t* out_pid,
                                 float* out_dist, uint32_t* out_count, uint32_t* out_counters);
 /* Same with every pointer in device memory, enqueued on `hip_stream` (a hipStream_t, may
- * be NULL) without synchronising: inputs/outputs stay resident in HBM. */
+ * be NULL) without synchronising: inputs/outputs stay resident in HBM.  A context is one
+ * `&mut Search`: its launches must be ordered among themselves (one stream, or explicit
+ * dependencies) — they share its visited slots and its work queue; use one context per
+ * concurrent stream.  Batches of up to ~100 queries through idist_search_batch (host
+ * pointers) cross PCIe through a pinned buffer owned by the context, without copy calls. */
 idist_status idist_search_batch_device(const idist_index* idx, idist_search_ctx* ctx,
                                        const void* d_queries, uint32_t nq, void* d_out_pid,
                                        void* d_out_dist, void* d_out_count, void* d_out_counters,
