@@ -3,8 +3,10 @@ written from the Rust source (/root/reference/instant-distance/src/lib.rs and ty
 
 Purpose: the reference cannot be built here (no rustc), so the C oracle is pinned only behaviourally by the reference's
 own known answers.  Two restatements made separately from the same source and agreeing array for array on the graph they
-build is the strongest extra evidence available; tests/test_oracle_restatement.py compares them.  Only the heuristic
-path is restated (the `select_heuristic(None)` splice depends on std's binary-search probe order).
+build is the strongest extra evidence available; tests/test_oracle_restatement.py compares them.  The
+`select_heuristic(None)` splice depends on the probe order of std's `slice::binary_search_by` (its comparator is
+reversed): restated here from the std source as of Rust 1.82+ (branch-free form) — best effort, like
+the oracle's.
 `Heuristic::extend_candidates` follows the code with its locks ignored (upstream it deadlocks: lib.rs:649 read-locks the
 node write-locked at :438), i.e. `node.set(i, pid)` (:516) is visible to later reads of the new node's row.
 
@@ -136,7 +138,30 @@ def rewrite(row, pids):
             break
 
 
-def build(D, n, ml, ef_construction, extend=False, keep_pruned=True):
+def binary_search_by(length, f):
+    """std::slice::binary_search_by (Rust >= 1.82): f(index) in {-1 Less, 0 Equal, +1 Greater}; returns the Ok/Err index."""
+    size, base = length, 0
+    if size == 0:
+        return 0
+    while size > 1:
+        half = size // 2
+        mid = base + half
+        base = base if f(mid) > 0 else mid
+        size -= half
+    c = f(base)
+    return base if c == 0 else base + (1 if c < 0 else 0)
+
+
+def zero_insert(row, idx, pid):
+    """ZeroNode::insert, types.rs:100-113."""
+    if idx >= len(row):
+        return
+    if row[idx] != INVALID:
+        row[idx + 1:] = row[idx:-1].copy()                 # copy_within(idx..end, idx + 1), end = len - 1
+    row[idx] = pid
+
+
+def build(D, n, ml, ef_construction, extend=False, keep_pruned=True, heuristic=True):
     """Hnsw::new with one thread (lib.rs:209-345; Construction::insert :437-528) on points given by their pairwise
     distance table D (n x n, already in PointId order).  Returns (zero [n][64], layers [[len][32]])."""
     zero = np.full((n, 2 * M), INVALID, dtype=np.uint32)
@@ -169,11 +194,23 @@ def build(D, n, ml, ef_construction, extend=False, keep_pruned=True):
             else:
                 search.search(dist_new, row_zero, num)
                 break
-        found = search.select_heuristic(dist_new, pair, row_zero, extend, keep_pruned)
-        for i, (_, pid) in enumerate(found):               # :481-516
-            dist_old = lambda x, pid=pid: float(D[pid][x])   # noqa: E731
-            res = insertion.add_neighbor_heuristic(new, row_zero(pid), dist_old, pair, row_zero, extend, keep_pruned)
-            rewrite(zero[pid], [p for _, p in res])
+        if heuristic:
+            found = search.select_heuristic(dist_new, pair, row_zero, extend, keep_pruned)
+        else:
+            found = search.nearest[:2 * M]                 # select_simple, :466-469, :758-760
+        for i, (distance, pid) in enumerate(found):        # :481-516
+            if heuristic:
+                dist_old = lambda x, pid=pid: float(D[pid][x])   # noqa: E731
+                res = insertion.add_neighbor_heuristic(new, row_zero(pid), dist_old, pair, row_zero, extend, keep_pruned)
+                rewrite(zero[pid], [p for _, p in res])
+            else:                                          # :497-515: the comparator is target.cmp(element), :510
+                def f(slot, pid=pid, distance=distance):
+                    third = int(zero[pid][slot])
+                    if third == INVALID:
+                        return 1                           # Ordering::Greater, :505-508
+                    other = float(D[pid][third])
+                    return (distance > other) - (distance < other)
+                zero_insert(zero[pid], binary_search_by(2 * M, f), new)
             zero[new][i] = pid                             # node.set(i, pid)
 
     for layer, lo, hi in ranges:                           # :304-329

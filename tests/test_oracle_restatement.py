@@ -25,6 +25,8 @@ def _tables(oracle, pts, q, metric):
     (80, 2, {"kind": "grid", "metric": 1, "ml": 0.6}),
     (60, 3, {"extend_candidates": 1}), (100, 4, {"extend_candidates": 1, "ml": 0.6, "ef_construction": 16}),
     (75, 2, {"extend_candidates": 1, "keep_pruned": 0, "metric": 1}),
+    (85, 3, {"has_heuristic": 0}), (120, 2, {"has_heuristic": 0, "ml": 0.6, "metric": 1}),
+    (90, 2, {"has_heuristic": 0, "kind": "grid", "metric": 1}),
 ])
 def test_two_restatements_build_the_same_graph(oracle, n, dim, kw):
     kw = dict(kw)
@@ -35,7 +37,8 @@ def test_two_restatements_build_the_same_graph(oracle, n, dim, kw):
     cfg = oracle.default_config(ef_search=25, **kw)
     oix = oracle.Index.build(pts, cfg, threads=1)
     D, Q = _tables(oracle, pts, q, cfg.metric)
-    zero, layers = pr.build(D, n, cfg.ml, cfg.ef_construction, bool(cfg.extend_candidates), bool(cfg.keep_pruned))
+    zero, layers = pr.build(D, n, cfg.ml, cfg.ef_construction, bool(cfg.extend_candidates), bool(cfg.keep_pruned),
+                            bool(cfg.has_heuristic))
     assert np.array_equal(zero, oix.zero)
     assert len(layers) == len(oix.layers)
     for a, b in zip(layers, oix.layers):
