@@ -50,3 +50,29 @@ def test_two_restatements_build_the_same_graph(oracle, n, dim, kw):
         assert len(got) == c
         assert [p for _, p in got] == want.pid[i, :c].tolist()
         assert np.array_equal(np.array([d for d, _ in got], dtype=np.float32).view(np.uint32), want.dist[i, :c].view(np.uint32))
+
+
+try:
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+except Exception:  # noqa: BLE001
+    given = None
+
+if given is not None:
+    @settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow],
+              derandomize=True)
+    @given(n=st.integers(1, 100), dim=st.integers(1, 5), ml=st.sampled_from([0.28853902, 0.45, 0.6, 0.75]),
+           efc=st.sampled_from([1, 3, 8, 30, 100]), metric=st.integers(0, 1), mode=st.sampled_from(["heur", "heur-nokeep", "extend", "simple"]),
+           lattice=st.booleans(), seed=st.integers(0, 10_000))
+    def test_two_restatements_agree_on_drawn_configs(oracle, n, dim, ml, efc, metric, mode, lattice, seed):
+        """The same comparison over drawn configurations (hypothesis, derandomised): sizes around the layer thresholds,
+        tiny ef_construction (push refuses ranks >= ef, lib.rs:713), lattices with exact ties, every selection mode."""
+        rng = np.random.default_rng(seed)
+        pts = (rng.integers(0, 3, size=(n, dim)) if lattice else rng.random((n, dim))).astype(np.float32)
+        cfg = oracle.default_config(ml=ml, ef_construction=efc, metric=metric, has_heuristic=int(mode != "simple"),
+                                    extend_candidates=int(mode == "extend"), keep_pruned=int(mode != "heur-nokeep"))
+        oix = oracle.Index.build(pts, cfg, threads=1)
+        D, _ = _tables(oracle, pts, pts[:0], metric)
+        zero, layers = pr.build(D, n, cfg.ml, efc, mode == "extend", mode != "heur-nokeep", mode != "simple")
+        assert np.array_equal(zero, oix.zero)
+        assert len(layers) == len(oix.layers) and all(np.array_equal(a, b) for a, b in zip(layers, oix.layers))
