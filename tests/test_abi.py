@@ -77,3 +77,14 @@ def test_compute_entry_points_fail_loudly_without_a_gpu(real_lib):
     assert b"no CPU path" in L.idist_last_error()
     with pytest.raises(_capi.IdistError):
         L.check(st)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/idist.h must compile as C (not only as C++), warnings-clean."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "idist.h"\nint main(void) { idist_config c; idist_index_info i; idist_build_stats s; '
+                   '(void)c; (void)i; (void)s; return 0; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(root, "include"), str(src)])
