@@ -169,6 +169,8 @@ struct Knobs {
     uint32_t tab_log2 = 0;        // IDIST_TAB_LOG2=<5..13>: size of the on-chip visited set (test knob: small sets exercise the overflow path)
     bool vis_bitmap = false;      // IDIST_VISITED=bitmap: search with bitmap + Bloom filter (16 waves per CU) instead of the on-chip set
     bool vis_onchip = false;      // IDIST_VISITED=onchip: the on-chip set whatever the policy says (test / A-B knob)
+    bool tab_ids = false;         // IDIST_TAB_FORMAT=ids: the on-chip set of a search keeps full ids (4 per bucket, frozen at 7/8) instead of
+                                  // 16-bit quotients (8 per bucket, single ids overflow) (test / A-B knob)
     bool no_zero_copy = false;    // IDIST_NO_ZERO_COPY=1: narrow host-pointer batches take the general (staged) path too (test / A-B knob)
     int tune = -1;                // IDIST_TUNE=<i> (tuning builds only, -DIDIST_TUNE): i-th experimental walk variant
     uint32_t quad_nq = 0xFFFFFFFFu;   // IDIST_QUAD_NQ: batches up to this many queries run four waves per query (default: two
@@ -182,6 +184,7 @@ struct Knobs {
         if (const char* e = getenv("IDIST_BLOOM")) k.bloom = e[0] != '0';
         if (const char* e = getenv("IDIST_VISITED")) { k.vis_bitmap = e[0] == 'b'; k.vis_onchip = e[0] == 'o'; }
         if (const char* e = getenv("IDIST_NO_ZERO_COPY")) k.no_zero_copy = e[0] != '0';
+        if (const char* e = getenv("IDIST_TAB_FORMAT")) k.tab_ids = e[0] == 'i';
         if (const char* e = getenv("IDIST_TAB_LOG2")) k.tab_log2 = std::min(13u, std::max(5u, (uint32_t)atoi(e)));
         return k;
     }
@@ -751,6 +754,9 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const bool on_chip = quad || wide_on_chip;
     const uint32_t tab_log2 = on_chip ? tab_fit : 0u;
     a.tab_log2 = tab_log2;
+    // the set stores 16-bit quotients (twice the ids in the same LDS) whenever n allows it: up to 33M points with 32 KB
+    a.ubits = on_chip ? q16_universe_bits(ix->n, tab_log2) : 0u;
+    const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits);
     const uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (on_chip ? 4u : 16u));   // quad: two workgroups per CU where registers allow
     CHK(ensure_slots(ctx, std::min(nq, resident), stream));
     ctx->last_ef = ef;
@@ -778,9 +784,18 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
 #define LAUNCH_SEARCH(NB_, RS_, TAIL_)                                                             \
     {                                                                                              \
-        if (quad) {                                                                                \
+        if (quad && q16) {                                                                         \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, true, true)>; \
+            IDIST_LAUNCH(kS, grid, 256, smem, stream, view, a);                                    \
+        } else if (quad) {                                                                         \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, true)>; \
             IDIST_LAUNCH(kS, grid, 256, smem, stream, view, a);                                    \
+        } else if (on_chip && classic && q16) {                                                    \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true, false, true)>; \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+        } else if (on_chip && q16) {                                                               \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } else if (on_chip && classic) {                                                           \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>;  \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \

@@ -311,10 +311,14 @@ enum : int { kWalkClassic = 0, kWalkLatency = 1, kWalkOverlap = 2 };
 //   instead of registers, bits 12-14 waves per SIMD the kernel is compiled for (0 = compiler's choice)
 //   bit 9 visited set kept on chip (LDS hash set, HBM bitmap only as overflow) instead of bitmap + Bloom filter
 //   bit 10 four-wave workgroup per walk: wave 0 leads (this routine), all four share each distance pass (QuadCtl)
-constexpr int walk_code(int mode, int rif = 0, bool q_lds = false, int waves = 0, bool vis_lds = false, bool quad = false) {
-    return mode | (rif << 4) | ((q_lds ? 1 : 0) << 8) | ((vis_lds ? 1 : 0) << 9) | ((quad ? 1 : 0) << 10) | (waves << 12);
+//   bit 11 the on-chip set stores 16-bit quotients instead of ids (twice the ids in the same LDS; search walks only)
+constexpr int walk_code(int mode, int rif = 0, bool q_lds = false, int waves = 0, bool vis_lds = false, bool quad = false,
+                        bool vis16 = false) {
+    return mode | (rif << 4) | ((q_lds ? 1 : 0) << 8) | ((vis_lds ? 1 : 0) << 9) | ((quad ? 1 : 0) << 10) |
+           ((vis16 ? 1 : 0) << 11) | (waves << 12);
 }
 constexpr bool walk_vis_lds(int code) { return ((code >> 9) & 1) != 0; }
+constexpr bool walk_vis16(int code) { return ((code >> 11) & 1) != 0; }
 constexpr bool walk_quad(int code) { return ((code >> 10) & 1) != 0; }
 constexpr int walk_mode(int code) { return code & 3; }
 constexpr int walk_rif(int code) { return (code >> 4) & 15; }
@@ -491,7 +495,7 @@ constexpr int kBloomLatWords = 1 << kBloomLatLog2Words;
 
 // Geometry of one slot: the bitmap is cut into blocks of 2^shift points (>= 512 points = one 64-B sector) such
 // that the dirty-block bitmap fits kDirtyMaxWords dwords of LDS whatever n is.
-constexpr uint32_t kDirtyMaxWords = 1024;                   // 4 KB of LDS: 32768 blocks
+constexpr uint32_t kDirtyMaxWords = 256;                    // 1 KB of LDS: 8192 blocks (128-B blocks at 10M points)
 struct VisGeom {
     uint32_t shift;        // log2(points per block), >= 9
     uint32_t blocks;       // blocks per slot
@@ -525,6 +529,9 @@ struct Visited {
     uint32_t count = 0;        // entries in tab (wave-uniform)
     bool spill = false;        // tab frozen, bitmap in use (wave-uniform)
     bool dirtied = false;      // the bitmap may hold set bits (wave-uniform)
+    // Quotient form of the on-chip set (search walks): see q16_* below
+    bool q16 = false;
+    uint32_t ubits = 0, rbits = 0;   // bits of the id universe (2^ubits >= n), bits of a remainder
 };
 __device__ __forceinline__ uint32_t bloom_h1(const Visited& v, uint32_t pid) { return (pid * 0x9E3779B1u) >> (27 - v.blog2); }
 __device__ __forceinline__ uint32_t bloom_h2(const Visited& v, uint32_t pid) { return (pid * 0x85EBCA6Bu + 0xC2B2AE35u) >> (27 - v.blog2); }
@@ -620,6 +627,70 @@ __device__ __forceinline__ int tab_insert(const Visited& v, uint32_t pid) {
         // another lane claimed the entry (a different id: a row never holds duplicates): look again
     }
 }
+// ---------------------------------------------------------------------------
+// Quotient form of the on-chip set (search walks): 16-bit entries, twice the ids in the same LDS.
+//
+// Both hashes are BIJECTIONS of the id universe [0, 2^ubits) (an odd multiplier, an xor-shift, an added constant, all
+// mod 2^ubits), so an id is determined by (which hash, bucket, remainder): the bucket index carries the top bits of the
+// hashed id, the entry only stores {which hash : 1, remainder : rbits} in 16 bits (0xFFFF = empty; rbits <= 14 keeps
+// bit 15 clear).  A bucket is eight entries = the same 16 B (one ds_read_b128) that hold four full ids in the plain form:
+// 16384 ids in 32 KB.  Membership stays EXACT: an id is in the set iff its first home bucket holds {0, r1} or its second
+// {1, r2}.
+//
+// No overflow chain and no freeze: an id that finds BOTH home buckets full goes to the HBM bitmap on its own (buckets
+// fill front to back and never lose an entry before the next clear, so "both full" holds for that id until then: it
+// is looked up in, and only in, the bitmap from then on; and an id that found room never was in the bitmap).  With two
+// choices and eight-entry buckets the table takes ~90 % of its capacity before the first id overflows, and the share
+// of ids that need the bitmap round trip then grows gradually instead of jumping to 100 % at a threshold.
+// ---------------------------------------------------------------------------
+enum : int { kQFound = 0, kQRoom = 1, kQFull = 2 };
+struct Q16Keys { uint32_t b1, t1, b2, t2; };
+__device__ __forceinline__ Q16Keys q16_keys(const Visited& v, uint32_t pid) {
+    const uint32_t um = (1u << v.ubits) - 1u, rm = (1u << v.rbits) - 1u;
+    const uint32_t h1 = (pid * 0x9E3779B1u) & um;
+    const uint32_t h2 = ((pid ^ (pid >> 7)) * 0x85EBCA6Bu + 0xC2B2AE35u) & um;
+    return Q16Keys{h1 >> v.rbits, h1 & rm, h2 >> v.rbits, (h2 & rm) | (1u << v.rbits)};
+}
+__device__ __forceinline__ bool q16_word_has(uint32_t w, uint32_t tt) {     // tt = t | t << 16
+    const uint32_t x = w ^ tt;
+    return (x & 0xFFFFu) == 0u || (x >> 16) == 0u;
+}
+__device__ __forceinline__ bool q16_has(const uint4 e, uint32_t t) {
+    const uint32_t tt = t | (t << 16);
+    return q16_word_has(e.x, tt) || q16_word_has(e.y, tt) || q16_word_has(e.z, tt) || q16_word_has(e.w, tt);
+}
+__device__ __forceinline__ int q16_fill(const uint4 e) {                     // entries in use = index of the first empty one
+    auto wf = [](uint32_t w) { return (w & 0xFFFFu) == 0xFFFFu ? 0 : ((w >> 16) == 0xFFFFu ? 1 : 2); };
+    const int a = wf(e.x), b = wf(e.y), c = wf(e.z), d = wf(e.w);
+    return a < 2 ? a : (b < 2 ? 2 + b : (c < 2 ? 4 + c : 6 + d));
+}
+__device__ __forceinline__ int q16_lookup(const Visited& v, uint32_t pid) {
+    const Q16Keys k = q16_keys(v, pid);
+    const uint4 e1 = *reinterpret_cast<const uint4*>(v.tab + 4u * k.b1);
+    const uint4 e2 = *reinterpret_cast<const uint4*>(v.tab + 4u * k.b2);
+    if (q16_has(e1, k.t1) || q16_has(e2, k.t2)) return kQFound;
+    return ((e1.w >> 16) == 0xFFFFu || (e2.w >> 16) == 0xFFFFu) ? kQRoom : kQFull;
+}
+// insert: kQRoom = it went in, kQFound = it was there, kQFull = both home buckets are full (the caller uses the bitmap).
+// Lanes of a wave insert distinct ids concurrently; the loser of a race for a word looks again.
+__device__ __forceinline__ int q16_insert(const Visited& v, uint32_t pid) {
+    const Q16Keys k = q16_keys(v, pid);
+    for (;;) {
+        const uint4 e1 = *reinterpret_cast<const uint4*>(v.tab + 4u * k.b1);
+        const uint4 e2 = *reinterpret_cast<const uint4*>(v.tab + 4u * k.b2);
+        if (q16_has(e1, k.t1) || q16_has(e2, k.t2)) return kQFound;
+        const int f1 = q16_fill(e1), f2 = q16_fill(e2);
+        if (f1 == 8 && f2 == 8) return kQFull;
+        const bool second = f2 < f1;
+        const uint4 e = second ? e2 : e1;
+        const int f = second ? f2 : f1;
+        const uint32_t t = second ? k.t2 : k.t1, b = second ? k.b2 : k.b1;
+        const int wi = f >> 1;
+        const uint32_t cur = wi == 0 ? e.x : (wi == 1 ? e.y : (wi == 2 ? e.z : e.w));
+        const uint32_t nw = (f & 1) ? ((cur & 0x0000FFFFu) | (t << 16)) : ((cur & 0xFFFF0000u) | t);
+        if (atomicCAS(&v.tab[4u * b + (uint32_t)wi], cur, nw) == cur) return kQRoom;
+    }
+}
 // Visited::clear (core/types.rs:48-58): empty the on-chip set / zero the dirty blocks.  Wave-uniform control flow.
 __device__ __forceinline__ void visited_clear(Visited& v) {
     const int lane = lane_id();
@@ -634,7 +705,7 @@ __device__ __forceinline__ void visited_clear(Visited& v) {
         v.count = 0;
         v.spill = false;
     }
-    if (!v.tab || v.dirtied) {
+    if (!v.tab || v.dirtied || v.q16) {                         // (quotient form: single ids overflow, no wave-uniform flag)
         const uint32_t wpb = 1u << (v.shift - 5);              // dwords per block (>= 16)
         for (uint32_t w0 = 0; w0 < v.dirty_words; w0 += 64) {
             const uint32_t mine = v.dirty[w0 + lane];
@@ -677,7 +748,9 @@ __device__ __forceinline__ bool visited_test_and_set(const Visited& v, uint32_t 
 // Visited::extend with one pid per lane (core/types.rs:42-46; cull) / a node known to be new.
 // (with the on-chip set the caller brackets it with visited_begin / visited_added like an expansion)
 __device__ __forceinline__ void visited_mark(const Visited& v, uint32_t pid) {
-    if (v.tab) {
+    if (v.q16) {
+        if (q16_insert(v, pid) != kQFull) return;
+    } else if (v.tab) {
         if (!v.spill) { (void)tab_insert(v, pid); return; }
         if (tab_find(v, pid)) return;
     }
@@ -688,7 +761,10 @@ __device__ __forceinline__ void visited_mark(const Visited& v, uint32_t pid) {
 // set (-1: not there)
 __device__ __forceinline__ bool visited_insert(const Visited& v, uint32_t pid, int& tab_idx) {
     tab_idx = -1;
-    if (v.tab) {
+    if (v.q16) {
+        const int r = q16_insert(v, pid);
+        if (r != kQFull) return r == kQRoom;
+    } else if (v.tab) {
         if (!v.spill) { tab_idx = tab_insert(v, pid); return tab_idx >= 0; }
         if (tab_find(v, pid)) return false;
     } else if (v.bloom && !bloom_maybe(v, pid)) {
@@ -971,7 +1047,72 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         const bool is_nb = lane < nvalid;
         [[maybe_unused]] const uint32_t tkA = IDIST_TICK();       // pop, peek and the adjacency row are in
 
-        if constexpr (!OVL) {
+        if constexpr (walk_vis16(LAT)) {
+            // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40, on the quotient set: one LDS round trip tells
+            // every neighbour apart — known / surely new (a home bucket has room: it never went to the bitmap) / both
+            // home buckets full (the bitmap decides).  The surely new ones go to the distance pass at once and enter the
+            // set while their rows are in flight; the test-and-set of the others is in flight during that pass, and
+            // those that turn out new get a second pass.  Keys are pushed in slot order afterwards, whichever pass
+            // computed them.
+            int stt = kQFound;
+            uint32_t vold = 0;
+            const uint32_t vbit = 1u << (nb_pid & 31u);
+            if (is_nb) {
+                if (nb_pid >= ix.n) st.status |= kStBadRow;
+                else {
+                    stt = q16_lookup(vis, nb_pid);
+                    if (stt == kQFull) vold = atomicOr(&vis.bits[nb_pid >> 5], vbit);
+                }
+            }
+            const bool sure = is_nb && stt == kQRoom, maybe = is_nb && stt == kQFull;
+            uint32_t my_d = 0;
+            const uint64_t sm = __ballot(sure);
+            wave_sync();
+            [[maybe_unused]] const uint32_t tk1 = IDIST_TICK();
+            if (sm) {
+                const int my = __popcll(sm & ((1ull << lane) - 1ull));
+                if (sure) act_pid[my] = nb_pid;                                         // keeps slot order
+                wave_sync();
+                auto mid = [&]() {
+                    if (sure && q16_insert(vis, nb_pid) == kQFull) {                    // filled up by this very expansion
+                        atomicOr(&vis.bits[nb_pid >> 5], vbit);
+                        visited_note(vis, nb_pid);
+                    }
+                };
+                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, __popcll(sm), mid);
+                else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, __popcll(sm), mid);
+                wave_sync();
+                if (sure) my_d = act_dist[my];
+            }
+            const bool late = maybe && (vold & vbit) == 0u;
+            if (late) visited_note(vis, nb_pid);
+            const uint64_t lm = __ballot(late);
+            wave_sync();
+            if (lm) {
+                const int my = __popcll(lm & ((1ull << lane) - 1ull));
+                if (late) act_pid[my] = nb_pid;
+                wave_sync();
+                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, __popcll(lm));
+                else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, __popcll(lm));
+                wave_sync();
+                if (late) my_d = act_dist[my];
+            }
+            const bool fresh = sure || late;
+            const int na = __popcll(sm) + __popcll(lm);
+            if (na) {
+#ifdef IDIST_PHASES
+                const uint32_t tk2 = IDIST_TICK();
+                ctr.t_pre += tk1 - tk0;
+                ctr.t_dist += tk2 - tk1;
+                ctr.t_post -= tk2;
+                tk_on = true;
+#endif
+                ctr.n_dist += (uint32_t)na;
+                uint64_t key = kMaxKey;
+                if (fresh) key = ((uint64_t)my_d << 32) | nb_pid;
+                w_push_keys(st, key, fresh);
+            }
+        } else if constexpr (!OVL) {
             // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
             bool fresh = false;
             int tab_idx = -1;

@@ -136,7 +136,8 @@ struct SearchArgs {
     uint32_t* status_host;  // [gridDim.x] in pinned host memory or null: per-workgroup copy of a non-zero status (host-pointer calls
                             // of narrow batches read it after the stream sync instead of copying the device word back)
     uint32_t use_bloom;     // LDS Bloom filter in front of the visited bitmap (walks without the on-chip set)
-    uint32_t tab_log2;      // log2(entries) of the on-chip visited set (walks with it)
+    uint32_t tab_log2;      // log2(entries) of the on-chip visited set (walks with it): 4 << tab_log2 bytes of LDS
+    uint32_t ubits;         // quotient form of that set: bits of the id universe, ceil(log2 n) (q16_* in idist_device.hpp)
     uint32_t tie_cap;       // capacity of the tie region (idist_config.tie_capacity)
 };
 // the LDS tail region (after the dirty-block bitmap) holds the Bloom filter or the on-chip visited set
@@ -146,6 +147,23 @@ __device__ __forceinline__ void visited_attach_tab(Visited& v, uint32_t* mem, ui
     v.tmask = (1u << (log2_entries - 2u)) - 1u;     // buckets of four ids
     v.tshift = 32u - (log2_entries - 2u);
     v.tlimit = (7u << log2_entries) / 8u;
+}
+// the same LDS as 2^(log2_entries - 2) buckets of eight 16-bit quotients (twice the ids), ids drawn from [0, 2^ubits)
+__host__ __device__ inline bool q16_applies(uint32_t log2_entries, uint32_t ubits) {
+    const uint32_t bbits = log2_entries - 2u;
+    return ubits > bbits && ubits - bbits <= 14u;      // a remainder + the which-hash bit stay below 0xFFFF (= empty)
+}
+__host__ __device__ inline uint32_t q16_universe_bits(uint32_t n, uint32_t log2_entries) {
+    uint32_t u = 1;
+    while (u < 32u && (1ull << u) < (uint64_t)n) u++;
+    const uint32_t bbits = log2_entries - 2u;
+    return u > bbits ? u : bbits + 1u;
+}
+__device__ __forceinline__ void visited_attach_q16(Visited& v, uint32_t log2_entries, uint32_t ubits) {
+    v.q16 = true;
+    v.ubits = ubits;
+    v.rbits = ubits - (log2_entries - 2u);
+    v.tlimit = 0xFFFFFFFFu;                            // never frozen: single ids overflow to the bitmap
 }
 
 // LAT: walk mode (kWalkClassic / kWalkLatency / kWalkOverlap, see search_layer).
@@ -173,6 +191,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
     Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words,
                 a.use_bloom ? sm.bloom : nullptr, walk_mode(LAT) == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
     if constexpr (walk_vis_lds(LAT)) visited_attach_tab(vis, sm.bloom, a.tab_log2);
+    if constexpr (walk_vis16(LAT)) visited_attach_q16(vis, a.tab_log2, a.ubits);
     uint32_t status = 0;
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
     for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;

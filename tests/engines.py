@@ -23,6 +23,16 @@ def build_emu():
     srcs = [os.path.join(ROOT, "instant-distance_amd", "csrc", f) for f in
             ("idist_capi.hip", "idist_kernels.hpp", "idist_device.hpp")]
     srcs += [os.path.join(ROOT, "tests", "simt", f) for f in ("hip_emu.hpp", "hip_emu.cpp")]
-    if not os.path.exists(EMU_SO) or os.path.getmtime(EMU_SO) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call([os.path.join(ROOT, "tests", "simt", "build_emu.sh")], stdout=subprocess.DEVNULL)
+    def stale():
+        return not os.path.exists(EMU_SO) or os.path.getmtime(EMU_SO) < max(os.path.getmtime(s) for s in srcs)
+
+    if stale():
+        # pytest-xdist workers race for the rebuild: one builds (into a temporary name, renamed when complete), the others wait
+        import fcntl
+
+        os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
+        with open(EMU_SO + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                subprocess.check_call([os.path.join(ROOT, "tests", "simt", "build_emu.sh")], stdout=subprocess.DEVNULL)
     return EMU_SO

@@ -11,14 +11,19 @@ import numpy as np
 
 INVALID = 0xFFFFFFFF
 
-# Variants of the graph walk (idist_device.hpp): the default keeps the visited set on chip (LDS hash set, HBM bitmap
-# as overflow — forced early with a tiny set); IDIST_VISITED=bitmap selects the bitmap + Bloom-filter walks (classic /
-# latency / overlap by batch width and IDIST_WALK).  All must give the reference's results.
+# Variants of the graph walk (idist_device.hpp): the default keeps the visited set on chip (LDS hash set of 16-bit
+# quotients, single ids overflow to the HBM bitmap — forced early with a tiny set; IDIST_TAB_FORMAT=ids: full ids,
+# frozen at 7/8); IDIST_VISITED=bitmap selects the bitmap + Bloom-filter walks (classic / latency / overlap by batch
+# width and IDIST_WALK).  All must give the reference's results.
 SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by index size and ef_search)", {}),
                    ("on-chip", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip"}),
                    ("four waves per query", {"IDIST_QUAD_NQ": "4000000000"}),
                    ("four waves per query, set of 128 ids then bitmap", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_LOG2": "7"}),
                    ("on-chip classic", {"IDIST_WALK": "classic", "IDIST_VISITED": "onchip"}),
+                   ("on-chip, full ids", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "ids"}),
+                   ("four waves per query, full ids, set of 128 ids then bitmap",
+                    {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_LOG2": "7", "IDIST_TAB_FORMAT": "ids"}),
+                   ("on-chip classic, full ids, set of 32 ids", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic", "IDIST_TAB_FORMAT": "ids"}),
                    ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7", "IDIST_QUAD_NQ": "0"}),
                    ("on-chip, set of 32 ids: bitmap from the start", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}),
                    ("bitmap overlap", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "0"}),
@@ -37,7 +42,8 @@ BUILD_VARIANTS = (("on-chip", {}),
 def search_variant(env):
     if isinstance(env, str):                     # a bare IDIST_LATENCY_NQ value
         env = {"IDIST_LATENCY_NQ": env}
-    keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ", "IDIST_BUILD_A2")
+    keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ", "IDIST_BUILD_A2",
+            "IDIST_TAB_FORMAT")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)
