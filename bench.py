@@ -1,11 +1,12 @@
 #!/usr/bin/env python
-"""bench.py — queries/sec at recall@10 >= 0.95 on 1M x 300-d f32 (BASELINE.json config C3),
-plus index build points/sec, on N MI355X GPUs of one node.
+"""bench.py — queries/sec at recall@10 >= 0.95 on 1M x 300-d f32 (BASELINE.json config C3, the default),
+plus index build points/sec, on N MI355X GPUs of one node.  `--config C2|C4|C5` runs the other BASELINE
+configurations through the same code and prints the same JSON shape.
 
 A "step" = one pass of Hnsw::search over this rank's batch of synthetic queries, inputs and
 outputs resident in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): rank 0
 builds the index, RCCL broadcasts it once over xGMI, every rank searches its own query
-shard (weak scaling: --nq queries per GPU), no collective inside the timed region.
+shard, no collective inside the timed region.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     HBM bound: algorithmic bytes per launch (B_q = n_dist*4*D + n_exp0*256 +
@@ -14,11 +15,15 @@ Prints ONE JSON line (rank 0).  Extra objects:
                measured with HIP events on the launch stream.
   cpu_baseline the CPU oracle (restated reference, NOT the Rust crate) searching the SAME graph
                on the host cores for a bounded query sample.
+  parity       (N = 1) the oracle's answers for a query sample at ef_search 100 / 200 / the timed one compared with
+               the GPU's: ids, order, counts, distance bits, work counters.
+  checks       (--check) size-independent properties of the results and of the built graph; tests/ assert on them.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -27,6 +32,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md chip table: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# BASELINE.json configs.  nq: queries per GPU per step ("weak") or of the whole job ("strong": C5's
+# 65,536-query batch is split over the GPUs).  gtq: queries with exact ground truth.  cpu_build: prefix the CPU oracle builds.
+CONFIGS = {
+    "C2": dict(n=100_000, dim=128, nq=10_000, split=False, gtq=0, cpu_build=100_000,
+               what="C2: 100k x 128-d f32, k=10, ef_search=100"),
+    "C3": dict(n=1_000_000, dim=300, nq=10_000, split=False, gtq=0, cpu_build=100_000,
+               what="C3: 1M x 300-d f32 (fastText-shape), Builder::build + 10k-query search"),
+    "C4": dict(n=1_000_000, dim=768, nq=65_536, split=False, gtq=4096, cpu_build=40_000,
+               what="C4: 1M x 768-d f32, 65,536 batched queries (ground truth by the -2QP^T MFMA filter + canonical re-rank)"),
+    "C5": dict(n=10_000_000, dim=768, nq=65_536, split=True, gtq=2048, cpu_build=40_000,
+               what="C5: 10M x 768-d f32, index replicated, 65,536-query batch sharded across the GPUs"),
+}
 
 
 def synth(torch, n, dim, seed, device, latent=32):
@@ -65,23 +83,71 @@ def effective_cores():
     return cores
 
 
+def scalar_calls(hnsw, ida, q_host, n_threads, calls):
+    """The reference's own concurrency model (core/lib.rs:352-356): T host threads share ONE index, each owns a
+    `Search` and issues scalar `Hnsw::search` calls (idist_search_batch with nq = 1, host pointers).  Returns the
+    aggregate calls/s.  The C entry point is called directly with preallocated buffers (ctypes drops the GIL for the
+    duration of the call), so Python's share per call is a few microseconds."""
+    import ctypes as C
+
+    from instant_distance_amd import _capi
+
+    L = _capi.lib()
+    ef, nq = hnsw._ef_search, q_host.shape[0]
+    searches = [ida.Search() for _ in range(n_threads)]
+    ctxs = [s._bind(hnsw) for s in searches]
+    gate = threading.Barrier(n_threads + 1)
+    errs = []
+
+    def work(t):
+        pid = np.empty(ef, np.uint32); dd = np.empty(ef, np.float32); cnt = np.zeros(1, np.uint32)
+        pp, pd, pc = _capi.u32p(pid), _capi.f32p(dd), _capi.u32p(cnt)
+        qs = [_capi.f32p(q_host[(t * calls + i) % nq]) for i in range(calls)]
+        fn, h, ctx = L.idist_search_batch, hnsw._h, ctxs[t]
+        rc = fn(h, ctx, qs[0], 1, pp, pd, pc, None)            # first call: the context's buffers come into being
+        gate.wait()
+        for i in range(calls):
+            rc |= fn(h, ctx, qs[i], 1, pp, pd, pc, None)
+        gate.wait()
+        if rc:
+            errs.append(rc)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for t in ts:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    gate.wait()
+    dt = time.perf_counter() - t0
+    for t in ts:
+        t.join()
+    if errs:
+        raise RuntimeError(f"idist_search_batch failed in a thread: status {errs}")
+    return n_threads * calls / dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--dim", type=int, default=300)
-    ap.add_argument("--nq", type=int, default=10_000, help="queries per GPU per step")
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS), help="BASELINE.json configuration (default C3, the metric's)")
+    ap.add_argument("--n", type=int, default=0, help="override the configuration's point count")
+    ap.add_argument("--dim", type=int, default=0)
+    ap.add_argument("--nq", type=int, default=0, help="queries per GPU per step (C5: of the whole job)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--ef", type=int, default=0, help="ef_search; 0 = smallest of 100/200/400/800 reaching the recall target")
     ap.add_argument("--recall-target", type=float, default=0.95)
-    ap.add_argument("--gt-queries", type=int, default=0, help="queries with exact ground truth (0 = all; MFMA -2QP^T filter + exact re-rank)")
+    ap.add_argument("--gt-queries", type=int, default=-1, help="queries with exact ground truth (0 = all; MFMA -2QP^T filter + exact re-rank)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries for the CPU baseline (0 = auto, ~15 s)")
+    ap.add_argument("--parity-queries", type=int, default=512, help="queries the oracle answers at every ef of the parity object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-build-sample", type=int, default=100_000, help="points of the prefix the CPU oracle builds (threaded)")
+    ap.add_argument("--cpu-build-sample", type=int, default=-1, help="points of the prefix the CPU oracle builds (threaded); 0 = skip")
+    ap.add_argument("--check", action="store_true", help="add the `checks` object (size-independent properties; used by tests/)")
+    ap.add_argument("--threads", default="1,4,16", help="host-thread counts of the scalar-call measurement ('' = skip)")
     ap.add_argument("--max-batch", type=int, default=0)
     args = ap.parse_args()
+    cfgd = CONFIGS[args.config]
 
     import torch
 
@@ -102,7 +168,10 @@ def main():
     import instant_distance_amd as ida
     from instant_distance_amd import dist as idd
 
-    n, dim, nq, k = args.n, args.dim, args.nq, args.k
+    n, dim, k = args.n or cfgd["n"], args.dim or cfgd["dim"], args.k
+    nq_cfg = args.nq or cfgd["nq"]
+    split = cfgd["split"]
+    nq_total = nq_cfg if split else nq_cfg * world
     builder = ida.Builder().max_batch(args.max_batch).device(local_rank)
 
     # ---- data + build (rank 0), replicate ----
@@ -118,9 +187,11 @@ def main():
         st = hnsw.build_stats()
         build = {"points_per_s": round(n / st.seconds, 1), "device_seconds": round(st.seconds, 3),
                  "wall_seconds": round(t_build, 3), "ef_construction": 100, "batches": int(st.n_batches),
-                 "n_dist": int(st.n_dist), "n_heur_dist": int(st.n_heur_dist), "n_updates": int(st.n_updates),
+                 "n_dist": int(st.n_dist), "n_sel_pairs": int(st.n_sel_pairs), "n_updates": int(st.n_updates),
                  "n_updates_memoised": int(st.n_updates_fast), "n_updates_full": int(st.n_updates_full),
-                 "n_heur_rows": int(st.n_heur_rows)}
+                 "n_heur_rows": int(st.n_heur_rows),
+                 "n_sel_pairs_note": "candidate pairs of select_heuristic decided here (by the Gram-matrix filter, a memoised "
+                                     "verdict or the canonical distance) — NOT the reference's early-exit count of distance calls"}
         # Bytes the build's algorithm moves AS EXECUTED HERE: the descents (B_q with ef_construction on the partial
         # graph), every point row fetched for select_heuristic / the neighbour re-selections (n_heur_rows; pairwise
         # reuse is on chip, memoised verdicts fetch nothing), and the adjacency rows read + rewritten.
@@ -131,49 +202,65 @@ def main():
                              "note": "all build kernels together over the build's device time; per-kernel PMC bytes: profiles/"}
     t_rep = 0.0
     replication = "single GPU"
+    rep = {}
     if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
         t0 = time.time()
         # RCCL broadcast into the replicas' device buffers; a failure fails the run (no silent per-rank rebuild:
         # that curve would not exercise the replication path)
         hnsw = idd.replicate_index(hnsw, builder, src=0)
         torch.cuda.synchronize()
-        replication = "rank 0 built, RCCL broadcast of points/zero/upper device buffers"
         dist.barrier()
         t_rep = time.time() - t0
+        replication = "rank 0 built, RCCL broadcast of points/zero/upper device buffers"
+        bufs = idd.device_views(hnsw, dev)
+        rep_bytes = int(sum(t.numel() for t in bufs if t is not None))
+        rep = {"replicate_bytes": rep_bytes, "replicate_GBps_per_destination": round(rep_bytes / max(t_rep, 1e-9) / 1e9, 2),
+               "replicate_note": "one broadcast tree over xGMI (7 links x ~153 GB/s per GPU); seconds include the first RCCL call's set-up"}
 
-    # ---- queries: held-out draws, seed+1; rank r takes [r*nq, (r+1)*nq) of the global batch ----
-    d_q_all = synth(torch, nq * world, dim, 123456790, dev)
-    lo, hi = idd.shard_range(nq * world, rank, world)
+    # ---- queries: held-out draws, seed+1; rank r takes its contiguous block of the global batch ----
+    d_q_all = synth(torch, nq_total, dim, 123456790, dev)
+    lo, hi = idd.shard_range(nq_total, rank, world)
     d_q = d_q_all[lo:hi].contiguous()
+    nq = hi - lo
+    del d_q_all
     search = ida.Search()
 
     def alloc_out(ef):
         return (torch.empty(nq, ef, dtype=torch.int32, device=dev), torch.empty(nq, ef, dtype=torch.float32, device=dev),
                 torch.empty(nq, dtype=torch.int32, device=dev), torch.empty(nq, 3, dtype=torch.int32, device=dev))
 
-    def run(ef, outs):
+    def run(outs, s=None):
         pid, dd, cnt, ctr = outs
-        hnsw.search_batch_device(search, d_q.data_ptr(), nq, pid.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
+        hnsw.search_batch_device(s or search, d_q.data_ptr(), nq, pid.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
                                  ctr.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
     # ---- ground truth (exact scan with the same canonical distance) + ef choice ----
-    gtq = min(args.gt_queries or nq, nq)
+    gt_req = cfgd["gtq"] if args.gt_queries < 0 else args.gt_queries
+    gtq = min(gt_req or nq, nq)
     truth, _ = hnsw.bruteforce(d_q[:gtq].cpu().numpy(), k)
-    sweep = {}
-    ef_list = [args.ef] if args.ef else [100, 200, 400, 800]
+    sweep, sample_out = {}, {}
+    pq = min(args.parity_queries, nq)
     chosen, recall = None, 0.0
-    for ef in ef_list:
+    for ef in ([args.ef] if args.ef else [100, 200, 400, 800]):
+        if chosen is not None and ef > 200:
+            break                                   # 100 and 200 are always on the curve; beyond only while the target is missed
         hnsw.set_ef_search(ef)
         outs = alloc_out(ef)
-        run(ef, outs)
+        run(outs)
         torch.cuda.synchronize()
         search.check_status()
         got = outs[0][:gtq, :k].cpu().numpy().astype(np.uint32)
         rec = float(np.mean([len(set(got[i].tolist()) & set(truth[i].tolist())) / k for i in range(gtq)]))
         sweep[str(ef)] = round(rec, 4)
-        chosen, recall = ef, rec
-        if rec >= args.recall_target:
-            break
+        sample_out[ef] = tuple(t[:pq].cpu().numpy() for t in outs)      # what the oracle is compared with below
+        if chosen is None and (rec >= args.recall_target or args.ef):
+            chosen, recall = ef, rec
+        last = (ef, rec)
+        del outs
+    if chosen is None:
+        chosen, recall = last
     if world > 1:   # every rank must time the same ef
         t = torch.tensor([chosen], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,14 +270,14 @@ def main():
 
     # ---- timed region ----
     for _ in range(args.warmup):
-        run(chosen, outs)
+        run(outs)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run(chosen, outs)
+        run(outs)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -204,26 +291,34 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = nq * world / (elapsed / args.steps)
+        value = nq_total / (elapsed / args.steps)
         kt = search.kernel_times_ms(args.steps)
         ctr = outs[3].cpu().numpy().astype(np.int64)
         launch_bytes = int((ctr[:, 0] * 4 * dim + ctr[:, 1] * 256 + ctr[:, 2] * 128 + 8 * chosen).sum())
         kernel_ms = float(kt.mean())
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch come from separate `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` passes over this same command
-        # (scripts/profile_bench.sh; PMC passes cannot run inside the timed process) — the committed result is quoted
-        traffic, traffic_source = None, None
+        # (scripts/profile_bench.sh; PMC passes cannot run inside the timed process): nothing is measured in THIS run
+        # (`traffic` = null), the newest committed result for the same workload is quoted beside it
+        quoted, quoted_src, mall = None, None, None
         import glob
         for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):   # newest round first
-            if os.path.exists(tp):
-                try:
-                    traffic = json.load(open(tp)).get("search_kernel_hbm_bytes_per_launch")
-                    traffic_source = os.path.relpath(tp, ROOT) + " (separate PMC passes of this command, not this run)"
-                    break
-                except Exception:
-                    traffic = None
+            try:
+                tj = json.load(open(tp))
+                if tj.get("config", "C3") != args.config:
+                    continue
+                quoted = tj.get("search_kernel_hbm_bytes_per_launch")
+                mall = tj.get("mall")
+                quoted_src = os.path.relpath(tp, ROOT) + " (separate PMC passes of this command, not this run)"
+                break
+            except Exception:  # noqa: BLE001
+                continue
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_in_run": None,
+                    "traffic_quoted": quoted, "traffic_source": quoted_src,
+                    "mall_note": "FETCH_SIZE counts the L2's fabric-side requests: Infinity-Cache (MALL) hits are inside it, so "
+                                 "'traffic' is fabric bytes, an upper bound of DRAM bytes; that is how an algorithmic rate can "
+                                 "exceed the 6.29 TB/s streaming-copy rate of the HBM stacks", "mall": mall,
                     "kernel": "search_kernel", "kernel_ms_avg": round(kernel_ms, 3),
                     "alg_bytes_per_launch": launch_bytes, "alg_bytes_per_query": round(launch_bytes / nq),
                     "n_dist_per_query": round(float(ctr[:, 0].mean()), 1), "n_exp0_per_query": round(float(ctr[:, 1].mean()), 1),
@@ -244,24 +339,67 @@ def main():
         for i in range(lat_n):
             hnsw.search_batch(q_host[i:i + 1], search)
         single["gpu_wall_ms_host_pointers"] = round((time.perf_counter() - t0) / lat_n * 1e3, 4)
+        # T host threads, one Search each, scalar calls on one shared index (core/lib.rs:352-356)
+        thr = {}
+        for T in [int(x) for x in args.threads.split(",") if x]:
+            thr[str(T)] = {"gpu_calls_per_s": round(scalar_calls(hnsw, ida, q_host, T, max(50, 1600 // T)), 1)}
+        single["threads"] = thr
         hnsw.search_batch(q_host, search)
         t0 = time.perf_counter()
         for _ in range(3):
             res_host = hnsw.search_batch(q_host, search, counters=True)
         pcie = {"qps": round(nq * 3 / (time.perf_counter() - t0), 1),
                 "note": f"idist_search_batch with host pointers: {nq * dim * 4 >> 20} MB of queries in, {nq * chosen * 8 >> 20} MB of results out per call, pageable memory"}
-        run(chosen, outs)                      # restore the full-batch outputs the checks below read
+        run(outs)                      # restore the full-batch outputs the checks below read
         torch.cuda.synchronize()
         assert np.array_equal(res_host.pid, outs[0].cpu().numpy().astype(np.uint32))
+        del res_host
 
-        cpu = None
+        checks = None
+        if args.check:
+            pid_t, dd_t, cnt_t = outs[0], outs[1], outs[2]
+            srt = torch.sort(pid_t, dim=1).values
+            outs2 = alloc_out(chosen)
+            run(outs2, ida.Search())                                     # a fresh Search: same answers (idempotence)
+            torch.cuda.synchronize()
+            ns = min(64, n)
+            self_q = d_pts[:ns].cpu().numpy()
+            sres = hnsw.search_batch(self_q, ida.Search())                # narrow batch: four waves per query
+            checks = {"count_is_ef": bool((cnt_t == min(chosen, n)).all().item()),
+                      "sorted_nearest_first": bool((dd_t[:, :-1] <= dd_t[:, 1:]).all().item()),
+                      "ids_unique_per_query": bool((srt[:, 1:] != srt[:, :-1]).all().item()),
+                      "idempotent": bool(torch.equal(outs2[0], pid_t) and torch.equal(outs2[1], dd_t)),
+                      "self_query_first_at_distance_0": bool(np.array_equal(sres.pid[:, 0], np.arange(ns)) and np.all(sres.distance[:, 0] == 0))}
+            del outs2, srt
+
+        cpu, parity = None, None
         if not args.no_cpu_baseline and world == 1:
             from oracle import pyoracle as po
             zero, layers = hnsw.into_parts()
+            if checks is not None:
+                valid = zero != 0xFFFFFFFF
+                checks["layer_sizes_match_reference"] = [l.shape[0] for l in layers] == po.layer_sizes(n)[1:]
+                checks["rows_prefix_valid"] = bool(np.all(valid[:, :-1] >= valid[:, 1:]))
+                checks["row_ids_in_range"] = bool(np.all(zero[valid] < n))
+                checks["min_degree"] = int(valid.sum(1).min())
+                checks["no_self_links"] = bool(not np.any(zero == np.arange(n, dtype=np.uint32)[:, None]))
+                del valid
             pts_h = d_pts.cpu().numpy()
-            oix = po.Index.from_arrays(pts_h, zero, layers, po.default_config(ef_search=chosen))
+            # (the oracle reads the arrays in place: a second host copy of 10M x 768 points would be another 31 GB)
+            oix = po.Index.from_arrays(pts_h, zero, layers, po.default_config(ef_search=chosen), borrow=True)
             cores = effective_cores()
-            q_h = d_q.cpu().numpy()
+            q_h = q_host
+            # ---- parity: ids / order / counts / distance bits / work counters of a query sample, per ef ----
+            parity = {"queries": pq}
+            for ef, (g_pid, g_dd, g_cnt, g_ctr) in sorted(sample_out.items()):
+                oix.set_ef_search(ef)
+                o = oix.search(q_h[:pq], threads=cores)
+                parity[f"ef{ef}"] = bool(np.array_equal(o.pid, g_pid.astype(np.uint32)) and
+                                         np.array_equal(o.dist.view(np.uint32), g_dd.view(np.uint32)) and
+                                         np.array_equal(o.count, g_cnt.astype(np.uint32)) and
+                                         np.array_equal(o.counters, g_ctr.astype(np.uint32)))
+            parity["all_identical"] = all(v for k_, v in parity.items() if k_.startswith("ef"))
+            oix.set_ef_search(chosen)
             # bounded sample: ~10-30 core-seconds of CPU work; best of 3 passes (thread start-up noise)
             probe = min(nq, 8 * cores)
             t0 = time.perf_counter(); oix.search(q_h[:probe], threads=cores); tp_ = time.perf_counter() - t0
@@ -276,14 +414,19 @@ def main():
                             and np.array_equal(ores.counters, outs[3][:sample].cpu().numpy().astype(np.uint32)))
             t0 = time.perf_counter(); oix.search(q_h[:200], threads=1)
             single["cpu_ms_per_query_one_thread"] = round((time.perf_counter() - t0) / min(200, nq) * 1e3, 4)
+            for T, row in thr.items():
+                nn = min(nq, max(200, 100 * int(T)))
+                t0 = time.perf_counter(); oix.search(q_h[:nn], threads=int(T))
+                row["cpu_oracle_calls_per_s"] = round(nn / (time.perf_counter() - t0), 1)
             # build baseline: the oracle's threaded build (per-layer parallel-for + per-node locks, the rayon path of
             # core/lib.rs:316-318) on a PREFIX of the same points — the rate falls with n, so this flatters the CPU
-            nb_ = min(n, args.cpu_build_sample)
-            t0 = time.perf_counter(); po.Index.build(pts_h[:nb_], po.default_config(), threads=cores); tb_ = time.perf_counter() - t0
-            build["cpu_baseline"] = {"value": round(nb_ / tb_, 1), "unit": "points/s", "cores": cores, "kind": "port",
-                                     "sample": f"first {nb_} of the {n} points, {cores} threads (prefix: optimistic for the CPU)",
-                                     "seconds": round(tb_, 2)}
-            build["gpu_over_cpu"] = round(build["points_per_s"] / build["cpu_baseline"]["value"], 1)
+            nb_ = min(n, cfgd["cpu_build"] if args.cpu_build_sample < 0 else args.cpu_build_sample)
+            if nb_:
+                t0 = time.perf_counter(); po.Index.build(pts_h[:nb_], po.default_config(), threads=cores); tb_ = time.perf_counter() - t0
+                build["cpu_baseline"] = {"value": round(nb_ / tb_, 1), "unit": "points/s", "cores": cores, "kind": "port",
+                                         "sample": f"first {nb_} of the {n} points, {cores} threads (prefix: optimistic for the CPU)",
+                                         "seconds": round(tb_, 2)}
+                build["gpu_over_cpu"] = round(build["points_per_s"] / build["cpu_baseline"]["value"], 1)
             cpu = {"value": round(sample / tc, 1), "unit": "queries/s", "cores": cores, "kind": "port",
                    "sample": f"first {sample} of the {nq} queries, same graph, ef_search={chosen}, {cores} threads = the "
                              f"container's CPU quota ({os.cpu_count()} logical CPUs visible) "
@@ -291,18 +434,21 @@ def main():
                    "seconds": round(tc, 2), "ids_identical_to_gpu": same,
                    "ids_distance_bits_counts_and_work_counters_identical_to_gpu": same_all}
 
-        out = {"metric": "queries/sec @ recall@10>=0.95, 1Mx300-d f32; index build points/sec",
+        out = {"metric": f"queries/sec @ recall@10>=0.95, {'1M' if n == 1_000_000 else n}x{dim}-d f32; index build points/sec",
                "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"C3: {n}x{dim}-d f32 fastText-shape synthetic (32-d latent, L2-normalised), "
+               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if split else "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{cfgd['what']} — {n}x{dim}-d f32 fastText-shape synthetic (32-d latent, L2-normalised), "
                                       f"Builder::build on GPU + {nq}-query Hnsw::search batch per GPU, k={k}",
-                          "n": n, "dim": dim, "queries_per_gpu": nq, "k": k, "ef_search": chosen,
+                          "name": args.config, "n": n, "dim": dim, "queries_per_gpu": nq, "k": k, "ef_search": chosen,
                           "recall_at_10": round(recall, 4), "recall_target": args.recall_target,
                           "recall_target_met": bool(recall >= args.recall_target), "recall_queries": gtq,
                           "ef_sweep_recall": sweep, "parallelism": f"query-shard x{world}, index replicated",
-                          "replication": replication, "replicate_seconds": round(t_rep, 3)},
-               "build": build, "roofline": roofline, "cpu_baseline": cpu, "single_query": single, "pcie_inclusive": pcie}
+                          "replication": replication, "replicate_seconds": round(t_rep, 3), **rep},
+               "build": build, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "single_query": single,
+               "pcie_inclusive": pcie}
+        if checks is not None:
+            out["checks"] = checks
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 2)
         print(json.dumps(out), flush=True)

@@ -23,19 +23,26 @@
  *   - there is no CPU fallback: without a gfx950 device every compute entry
  *     point fails with IDIST_ERR_NO_DEVICE.
  *
- * Environment knobs (measurement and test only; none changes a search result or an exact-mode build):
- *   IDIST_LATENCY_NQ=<n>   batches of <= n queries (and build steps of <= n inserts) run the latency
- *                          variant of the graph walk; default 1024, 0 = never
- *   IDIST_WALK=classic     full batches / wide build steps with the classic walk instead of the overlap walk
- *   IDIST_BLOOM=0          no LDS Bloom filter in front of the visited bitmap
+ * Environment knobs (measurement and test only; none changes a search result or an exact-mode build; sampled once
+ * per context / per build; the full table with what each one is for is DESIGN.md's appendix):
+ *   IDIST_WALK=classic      one distance round in flight, no adjacency prefetch (search and build descents)
+ *   IDIST_VISITED=bitmap|onchip  force the bitmap + Bloom-filter walk / the on-chip visited set, whatever the policy says
+ *   IDIST_TAB_LOG2=<5..13>  LDS of the on-chip visited set, 4 << n bytes (small sets exercise the overflow to the
+ *                           bitmap; the build clamps it to >= 8); also forces the on-chip walk
+ *   IDIST_TAB_FORMAT=ids    the on-chip set of a search keeps full ids (frozen at 7/8) instead of 16-bit quotients
+ *   IDIST_QUAD_NQ=<n>       batches of <= n queries run four waves per query (default two queries per CU; 0 = never)
+ *   IDIST_LATENCY_NQ=<n>    bitmap walk only: batches of <= n queries run its latency variant (default 1024)
+ *   IDIST_BLOOM=0           bitmap walk without the LDS Bloom filter
+ *   IDIST_NO_ZERO_COPY=1    narrow host-pointer batches take the staged-copy path too
  *   IDIST_BRUTEFORCE=scan|mfma, IDIST_BF_SAMPLE=<n>   force a path of idist_bruteforce / its sample size
- *   IDIST_BUILD_PIPELINE=0 concurrent builds without the two-stream pipeline (a new point then sees all
- *                          points up to the previous step instead of the one before; graphs differ, quality
- *                          does not)
- *   IDIST_BUILD_CHECK=1    self-check at the end of a pipelined build: both copies of the zero layer must agree
- *   IDIST_BUILD_A_WAVES=<n> descent waves per CU in the pipelined schedule (default 10)
- *   IDIST_BUILD_RT, IDIST_BUILD_RT2, IDIST_BUILD_NO_FAST, IDIST_BUILD_CHUNK  build tile sizes / route every
- *                          neighbour update through the from-scratch kernel / updates per work-queue dequeue
+ *   IDIST_BUILD_PIPELINE=0  concurrent builds without the two-stream pipeline (a new point then sees all points up
+ *                           to the previous step instead of the one before; graphs differ, quality does not)
+ *   IDIST_BUILD_CHECK=1     self-check at the end of a pipelined build: both copies of the zero layer must agree
+ *   IDIST_BUILD_A_WAVES=<1..4>  descent waves per CU in the pipelined schedule (default 3)
+ *   IDIST_BUILD_A2=tile     new points' select_heuristic with the LDS-tile kernel instead of the Gram matrix on MFMA
+ *   IDIST_BUILD_NO_FAST=1   every neighbour update through the from-scratch kernel (no memoised re-selection)
+ *   IDIST_BUILD_NO_DLOG=1   the memoised re-selection recomputes every distance instead of looking it up
+ *   IDIST_BUILD_RT, IDIST_BUILD_RT2, IDIST_BUILD_CHUNK  build tile sizes / updates per work-queue dequeue
  */
 #ifndef IDIST_H
 #define IDIST_H
@@ -130,7 +137,8 @@ typedef struct idist_build_stats {
     uint64_t n_dist;        /* descent distance evaluations (Search::push past `visited`) */
     uint64_t n_exp0;        /* zero-array expansions */
     uint64_t n_expU;        /* snapshot (UpperNode) expansions */
-    uint64_t n_heur_dist;   /* pairwise distances inside select_heuristic + neighbour re-selection */
+    uint64_t n_sel_pairs;   /* candidate pairs of select_heuristic DECIDED here (by the Gram-matrix filter, a memoised
+                               verdict or the canonical distance) — this engine's work, not the reference's count */
     uint64_t n_heur_rows;   /* candidate rows staged for select_heuristic */
     uint64_t n_updates;     /* neighbour rows rewritten (ZeroNode::rewrite) */
     uint64_t n_updates_fast; /* ... of which through the memoised re-selection */
@@ -138,6 +146,10 @@ typedef struct idist_build_stats {
     uint64_t n_batches;
     double seconds;         /* device time of the whole build (HIP events) */
     uint64_t tie_overflow;  /* 1 if the tie capacity was exceeded during the build (only with IDIST_TIES_DROP) */
+    uint64_t n_heur_ref;    /* distance calls of select_heuristic / add_neighbor_heuristic exactly as the reference makes them
+                               (early-exit `any`, core/lib.rs:676-679; the pushes of :626-629) — available (non-zero) only when
+                               the whole build ran through the reference-order kernels: max_batch = 1 with
+                               IDIST_BUILD_A2=tile IDIST_BUILD_NO_FAST=1, or extend_candidates; tests compare it with the oracle */
 } idist_build_stats;
 
 /* ---- library ------------------------------------------------------------ */
@@ -199,11 +211,6 @@ idist_status idist_index_get_info(const idist_index* idx, idist_index_info* out)
 idist_status idist_index_device_buffers(const idist_index* idx, idist_device_buffers* out);
 /* Hnsw.ef_search is a field of the index (core/lib.rs:195); bench sweeps change it. */
 idist_status idist_index_set_ef_search(idist_index* idx, uint32_t ef_search);
-/* Moves the index's device buffers (points, zero, upper) into fresh allocations.  Where the index and a context's
- * visited array land in HBM relative to each other moves the search kernel's time by ~10 %;
- * idist_search_ctx_new chooses the visited array against the index as it is placed at that moment, so call this
- * before creating contexts, not after.  No search may be in flight on the index; contexts stay valid. */
-idist_status idist_index_rehome(idist_index* idx);
 void idist_index_free(idist_index* idx);
 
 /* ---- search ------------------------------------------------------------- */
@@ -216,6 +223,11 @@ void idist_index_free(idist_index* idx);
  * A context is bound to the index it was created for (by identity, not by address). */
 idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_search_ctx** out);
 void idist_search_ctx_free(idist_search_ctx* ctx);
+/* Back `slots` query slots now (Vec::reserve on the Search's scratch).  Growing is the one operation of a context that
+ * synchronises the whole device and allocates (the old bitmaps may still be in use by launches on any stream): a launch
+ * wider than the slots a context has grows it first, so a caller of idist_search_batch_device who needs launches that
+ * never synchronise (stream capture, other contexts busy on the device) reserves min(widest batch, a full chip) up front. */
+idist_status idist_search_ctx_reserve(idist_search_ctx* ctx, uint32_t slots);
 
 /* Hnsw::search, core/lib.rs:352-383, for nq queries at once (nq == 1 backs the scalar
  * call).  Results are Search.nearest: <= ef_search (pid, distance) pairs, nearest first
@@ -261,6 +273,14 @@ idist_status idist_search_ctx_kernel_times(idist_search_ctx* ctx, float* ms, uin
  * replicas through idist_index_device_buffers — is instant-distance_amd/dist.py.) */
 idist_status idist_replicate(const idist_index* root, const int32_t* devices, uint32_t n_devices,
                              idist_index** replicas);
+/* The same replication as ONE RCCL broadcast per buffer (points, zero, upper) over a single-process communicator
+ * (ncclCommInitAll over the root's device and the distinct destination devices, ncclBroadcast inside one group,
+ * one stream per device): RCCL picks the ring / tree over xGMI instead of the root feeding every peer itself.
+ * librccl.so is loaded on first use (dlopen; IDIST_ERR_UNSUPPORTED if it is missing).  A destination on the root's
+ * own device is served inside the same broadcast (recvbuff != sendbuff on the root rank).  *seconds (optional):
+ * wall time of the broadcasts, communicator set-up excluded. */
+idist_status idist_replicate_rccl(const idist_index* root, const int32_t* devices, uint32_t n_devices,
+                                  idist_index** replicas, double* seconds);
 /* Hnsw::search for nq host queries over n_shards (replica, context) pairs: the queries are cut into the
  * contiguous ranges [nq*i/n_shards, nq*(i+1)/n_shards) — what a caller partitioning over threads does —
  * each searched by idist_search_batch on its own GPU from its own host thread, results written to the same

@@ -69,9 +69,9 @@ class DeviceBuffers(C.Structure):
 class BuildStats(C.Structure):
     _fields_ = [
         ("n_dist", C.c_uint64), ("n_exp0", C.c_uint64), ("n_expU", C.c_uint64),
-        ("n_heur_dist", C.c_uint64), ("n_heur_rows", C.c_uint64), ("n_updates", C.c_uint64),
+        ("n_sel_pairs", C.c_uint64), ("n_heur_rows", C.c_uint64), ("n_updates", C.c_uint64),
         ("n_updates_fast", C.c_uint64), ("n_updates_full", C.c_uint64),
-        ("n_batches", C.c_uint64), ("seconds", C.c_double), ("tie_overflow", C.c_uint64),
+        ("n_batches", C.c_uint64), ("seconds", C.c_double), ("tie_overflow", C.c_uint64), ("n_heur_ref", C.c_uint64),
     ]
 
 
@@ -100,10 +100,10 @@ SYMBOLS = {
     "idist_index_get_info": (C.c_int32, [_vp, C.POINTER(IndexInfo)]),
     "idist_index_device_buffers": (C.c_int32, [_vp, C.POINTER(DeviceBuffers)]),
     "idist_index_set_ef_search": (C.c_int32, [_vp, C.c_uint32]),
-    "idist_index_rehome": (C.c_int32, [_vp]),
     "idist_index_free": (None, [_vp]),
     "idist_search_ctx_new": (C.c_int32, [_vp, C.c_uint32, C.POINTER(_vp)]),
     "idist_search_ctx_free": (None, [_vp]),
+    "idist_search_ctx_reserve": (C.c_int32, [_vp, C.c_uint32]),
     "idist_search_batch": (C.c_int32, [_vp, _vp, _f32p, C.c_uint32, _u32p, _f32p, _u32p, _u32p]),
     "idist_search_batch_device": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "idist_search_ctx_status": (C.c_int32, [_vp]),
@@ -111,6 +111,7 @@ SYMBOLS = {
     "idist_search_ctx_last_kernel_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
     "idist_search_ctx_kernel_times": (C.c_int32, [_vp, _f32p, C.c_uint32, _u32p]),
     "idist_replicate": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(_vp)]),
+    "idist_replicate_rccl": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(_vp), C.POINTER(C.c_double)]),
     "idist_search_batch_sharded": (C.c_int32, [C.POINTER(_vp), C.POINTER(_vp), C.c_uint32, _f32p, C.c_uint32, _u32p, _f32p,
                                                _u32p, _u32p]),
     "idist_distance_batch": (C.c_int32, [_vp, _f32p, C.c_uint32, _u32p, C.c_uint32, _f32p]),

@@ -229,6 +229,11 @@ class Search:
         except Exception:
             pass
 
+    def reserve(self, hnsw: "Hnsw", slots: int):
+        """Back `slots` query slots now (idist_search_ctx_reserve): later launches up to that width never synchronise
+        the device to grow the context."""
+        _lib().check(_lib().idist_search_ctx_reserve(self._bind(hnsw), int(slots)))
+
     def kernel_times_ms(self, last: int = 64) -> np.ndarray:
         """HIP-event durations of the most recent search kernels launched through this Search."""
         out = np.zeros(last, dtype=np.float32)
@@ -391,10 +396,6 @@ class Hnsw:
         _lib().check(_lib().idist_index_build_stats(self._h, C.byref(st)))
         return st
 
-    def rehome(self):
-        """Move the index's device buffers into fresh allocations (placement in HBM, see idist_index_rehome)."""
-        _lib().check(_lib().idist_index_rehome(self._h))
-
     def set_ef_search(self, ef: int):
         _lib().check(_lib().idist_index_set_ef_search(self._h, int(ef)))
         self._ef_search = int(ef)
@@ -439,12 +440,19 @@ class Hnsw:
                                             C.c_void_p(stream) if stream else None))
 
     # -- several GPUs of one node (single process; the multi-process flavour is dist.py) --
-    def replicate(self, devices: Sequence[int]) -> list["Hnsw"]:
-        """One copy of this index per entry of `devices`, device to device over xGMI (idist_replicate).
-        The replicas share this index's host copy of the points (`Item.point` works on every replica)."""
+    def replicate(self, devices: Sequence[int], rccl: bool = False) -> list["Hnsw"]:
+        """One copy of this index per entry of `devices`, device to device over xGMI: peer copies from the root
+        (idist_replicate) or, `rccl=True`, one RCCL broadcast per buffer (idist_replicate_rccl; its wall time is left in
+        `self.last_replicate_seconds`).  The replicas share this index's host copy of the points (`Item.point` works on
+        every replica)."""
         devs = (C.c_int32 * max(len(devices), 1))(*[int(d) for d in devices])
         outs = (C.c_void_p * max(len(devices), 1))()
-        _lib().check(_lib().idist_replicate(self._h, devs, len(devices), outs))
+        if rccl:
+            secs = C.c_double(0.0)
+            _lib().check(_lib().idist_replicate_rccl(self._h, devs, len(devices), outs, C.byref(secs)))
+            self.last_replicate_seconds = secs.value
+        else:
+            _lib().check(_lib().idist_replicate(self._h, devs, len(devices), outs))
         return [Hnsw(C.c_void_p(outs[i]), self.points, self._ef_search) for i in range(len(devices))]
 
     @staticmethod

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -327,6 +328,9 @@ idist_status device_status_to_code(uint32_t st, int32_t tie_policy) {
     if ((st & kStTieOverflow) && tie_policy == IDIST_TIES_STRICT)
         return fail(IDIST_ERR_TIE_OVERFLOW, "more than %d live equidistant candidates beyond ef "
                     "(raise idist_config.tie_capacity, or tie_policy = IDIST_TIES_DROP keeps the nearest ones and goes on)", (int)g_tie_cap_msg);
+    if (st & kStQueue)
+        return fail(IDIST_ERR_INTERNAL, "a search launch found its context's work queue where no launch of this context left it: the "
+                    "launches of one context must run once each, in the order they were enqueued (no graph replay, one stream)");
     if (st & kStGuard) return fail(IDIST_ERR_INTERNAL, "device-side loop guard tripped");
     return IDIST_OK;
 }
@@ -392,7 +396,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     uint32_t* d_dlog_pd = nullptr;
     uint32_t* d_wcount = nullptr;
     uint32_t *d_row_nsel = nullptr, *d_slow = nullptr, *d_nbr_aux = nullptr;
-    unsigned long long* d_stats = nullptr; // [8]
+    unsigned long long* d_stats = nullptr; // [16]
     const size_t n_edges = (size_t)cap * IDIST_M2;
     const size_t n_touch = std::min<size_t>(n_edges, n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -460,8 +464,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     BCHK(hipMalloc((void**)&d_touched, n_touch * 4));
     BCHK(hipMalloc((void**)&d_small, 256));
     BCHK(hipMemset(d_small, 0, 256));
-    BCHK(hipMalloc((void**)&d_stats, 64));
-    BCHK(hipMemset(d_stats, 0, 64));
+    BCHK(hipMalloc((void**)&d_stats, 128));
+    BCHK(hipMemset(d_stats, 0, 128));
     BCHK(hipEventCreate(&e0));
     BCHK(hipEventCreate(&e1));
 
@@ -636,21 +640,23 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     float ms = 0;
     BCHK(hipEventElapsedTime(&ms, e0, e1));
     uint32_t small[8] = {0};
-    unsigned long long stats[8] = {0};
+    unsigned long long stats[16] = {0};
     BCHK(hipMemcpy(&small[6], d_status, 4, hipMemcpyDeviceToHost));
-    BCHK(hipMemcpy(stats, d_stats, 64, hipMemcpyDeviceToHost));
+    BCHK(hipMemcpy(stats, d_stats, 128, hipMemcpyDeviceToHost));
 #undef BCHK
     release();
     ix->stats.n_dist = stats[0];
     ix->stats.n_exp0 = stats[1];
     ix->stats.n_expU = stats[2];
-    ix->stats.n_heur_dist = stats[3];
+    ix->stats.n_sel_pairs = stats[3];
     ix->stats.n_heur_rows = stats[4];
     ix->stats.n_updates = stats[5];
     ix->stats.n_batches = n_batches;
     ix->stats.seconds = ms * 1e-3;
     ix->stats.n_updates_fast = stats[6];
     ix->stats.n_updates_full = stats[7];
+    // the reference's own count exists only where every selection ran in the reference's order
+    ix->stats.n_heur_ref = (ext || (cfg.has_heuristic && no_fast && !a2_mfma && cap == 1)) ? stats[8] : 0;
     if (prog) { prog->slot[0] = n; prog->slot[1] = 0; }
     ix->stats.tie_overflow = (small[6] & kStTieOverflow) ? 1 : 0;
     return device_status_to_code(small[6], cfg.tie_policy);
@@ -697,7 +703,8 @@ idist_status check_ctx(const idist_index* idx, const idist_search_ctx* ctx) {
 idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stream) {
     if (want <= ctx->slots) return IDIST_OK;
     uint32_t s = 1;
-    while (s < want) s <<= 1;                                    // few distinct sizes: 1, 2, 4, ... up to the cap
+    while (s < want) s <<= 1;                                    // few distinct sizes: powers of two up to the cap ...
+    if (ctx->slots) s = std::max(s, ctx->slots * 8u);            // ... and at least 8x per step: growing synchronises the device
     const uint32_t cap = ctx->slots_req ? ctx->slots_req : default_slots(ctx->idx);
     s = std::max(std::min(s, cap), 1u);
     if (s <= ctx->slots) return IDIST_OK;
@@ -757,7 +764,10 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // the set stores 16-bit quotients (twice the ids in the same LDS) whenever n allows it: up to 33M points with 32 KB
     a.ubits = on_chip ? q16_universe_bits(ix->n, tab_log2) : 0u;
     const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits);
-    const uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (on_chip ? 4u : 16u));   // quad: two workgroups per CU where registers allow
+    uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (on_chip ? 4u : 16u));   // quad: two workgroups per CU where registers allow
+#ifdef IDIST_TUNE
+    if (const char* e = getenv("IDIST_WAVES_PER_CU")) resident = (uint32_t)ix->n_cu * (uint32_t)std::max(1, atoi(e));   // tuning builds only
+#endif
     CHK(ensure_slots(ctx, std::min(nq, resident), stream));
     ctx->last_ef = ef;
     a.out_pid = d_pid;
@@ -833,6 +843,12 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
             TUNE_CASE(7, walk_code(kWalkOverlap, 2, false, 1, true))
             TUNE_CASE(8, walk_code(kWalkOverlap, 4, false, 0, true))
             TUNE_CASE(9, walk_code(kWalkOverlap, 5, false, 1, true))
+            // quotient set (needs q16 = true, i.e. no IDIST_TAB_FORMAT=ids): one / two waves per SIMD (512 / 256 registers)
+            TUNE_CASE(10, walk_code(kWalkOverlap, 4, false, 1, true, false, true))
+            TUNE_CASE(11, walk_code(kWalkOverlap, 4, false, 2, true, false, true))
+            TUNE_CASE(12, walk_code(kWalkOverlap, 3, false, 2, true, false, true))
+            TUNE_CASE(13, walk_code(kWalkOverlap, 2, false, 2, true, false, true))
+            TUNE_CASE(14, walk_code(kWalkOverlap, 4, true, 2, true, false, true))
             default: return fail(IDIST_ERR_INVALID_ARG, "IDIST_TUNE=%d: no such variant", ctx->knobs.tune);
         }
 #undef TUNE_CASE
@@ -1081,27 +1097,6 @@ idist_status idist_index_set_ef_search(idist_index* idx, uint32_t ef_search) {
     return IDIST_OK;
 }
 
-idist_status idist_index_rehome(idist_index* idx) {
-    if (!idx) return fail(IDIST_ERR_INVALID_ARG, "idx is null");
-    HIPCHK(hipSetDevice(idx->device));
-    HIPCHK(hipDeviceSynchronize());
-    const size_t pb = std::max<size_t>((size_t)idx->n * idx->L.stride * 4, 256), zb = std::max<size_t>((size_t)idx->n * IDIST_M2 * 4, 256),
-                 ub = std::max<size_t>(idx->upper_rows * IDIST_M * 4, 256);
-    float* np_ = nullptr;
-    uint32_t *nz = nullptr, *nu = nullptr;
-    if (hipMalloc((void**)&np_, pb) != hipSuccess || hipMalloc((void**)&nz, zb) != hipSuccess || hipMalloc((void**)&nu, ub) != hipSuccess ||
-        hipMemcpy(np_, idx->d_points, pb, hipMemcpyDeviceToDevice) != hipSuccess ||
-        hipMemcpy(nz, idx->d_zero, zb, hipMemcpyDeviceToDevice) != hipSuccess ||
-        hipMemcpy(nu, idx->d_upper, ub, hipMemcpyDeviceToDevice) != hipSuccess) {
-        hipFree(np_); hipFree(nz); hipFree(nu);
-        return fail(IDIST_ERR_HIP, "rehome: %s", hipGetErrorString(hipGetLastError()));
-    }
-    HIPCHK(hipDeviceSynchronize());
-    hipFree(idx->d_points); hipFree(idx->d_zero); hipFree(idx->d_upper);
-    idx->d_points = np_; idx->d_zero = nz; idx->d_upper = nu;
-    return IDIST_OK;
-}
-
 void idist_index_free(idist_index* idx) {
     if (!idx) return;
     hipSetDevice(idx->device);
@@ -1163,6 +1158,15 @@ void idist_search_ctx_free(idist_search_ctx* c) {
     }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
+}
+
+idist_status idist_search_ctx_reserve(idist_search_ctx* ctx, uint32_t slots) {
+    if (!ctx) return fail(IDIST_ERR_INVALID_ARG, "ctx is null");
+    // (the index is only read for its device: a context outlives nothing it points to, see check_ctx)
+    const uint32_t cap = ctx->slots_req ? ctx->slots_req : 0xFFFFFFFFu;
+    CHK(ensure_slots(ctx, std::min(std::max(slots, 1u), cap), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));                   // the new bitmaps are cleared before any stream may use them
+    return IDIST_OK;
 }
 
 idist_status idist_search_batch_device(const idist_index* idx, idist_search_ctx* ctx, const void* d_queries,
@@ -1381,6 +1385,125 @@ idist_status idist_replicate(const idist_index* root, const int32_t* devices, ui
     drop_streams();
     hipSetDevice(root->device);
     return IDIST_OK;
+}
+
+// ---- the same replication as RCCL broadcasts (one process, one communicator over the devices involved) ----
+#ifndef IDIST_EMU
+#include <dlfcn.h>
+namespace {
+// the six RCCL entry points this file needs, resolved on first use: libidist.so carries no link-time dependency on
+// librccl (a process that never replicates never loads it; a process that already holds one — torch's — shares it)
+struct Rccl {
+    typedef void* comm_t;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+    Rccl() {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) { why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p && why.empty()) why = std::string("librccl: no symbol ") + n; return p; };
+        CommInitAll = (int (*)(comm_t*, int, const int*))sym("ncclCommInitAll");
+        CommDestroy = (int (*)(comm_t))sym("ncclCommDestroy");
+        GroupStart = (int (*)())sym("ncclGroupStart");
+        GroupEnd = (int (*)())sym("ncclGroupEnd");
+        Broadcast = (int (*)(const void*, void*, size_t, int, int, comm_t, hipStream_t))sym("ncclBroadcast");
+        GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+        ok = why.empty();
+    }
+    static Rccl& get() { static Rccl r; return r; }
+};
+constexpr int kNcclUint8 = 1;   // ncclDataType_t::ncclUint8 (rccl.h)
+}  // namespace
+#endif
+
+idist_status idist_replicate_rccl(const idist_index* root, const int32_t* devices, uint32_t n_devices, idist_index** replicas,
+                                  double* seconds) {
+    if (!root || !replicas || (n_devices && !devices)) return fail(IDIST_ERR_INVALID_ARG, "null argument");
+    if (seconds) *seconds = 0.0;
+#ifdef IDIST_EMU
+    return idist_replicate(root, devices, n_devices, replicas);       // (the CPU emulator of tests/simt has no RCCL: same result)
+#else
+    for (uint32_t i = 0; i < n_devices; i++) replicas[i] = nullptr;
+    if (n_devices == 0) return IDIST_OK;
+    Rccl& R = Rccl::get();
+    if (!R.ok) return fail(IDIST_ERR_UNSUPPORTED, "idist_replicate_rccl: %s", R.why.c_str());
+    // ranks: the root's device first, then every other distinct destination device
+    std::vector<int> devs{root->device};
+    for (uint32_t i = 0; i < n_devices; i++)
+        if (std::find(devs.begin(), devs.end(), (int)devices[i]) == devs.end()) devs.push_back((int)devices[i]);
+    const int nr = (int)devs.size();
+    std::vector<Rccl::comm_t> comms(nr, nullptr);
+    std::vector<hipStream_t> streams(nr, nullptr);
+    std::vector<int> first(nr, -1);                                   // the replica each rank receives into
+    auto cleanup = [&](idist_status s) {
+        const std::string keep = g_err;
+        for (int r = 0; r < nr; r++) {
+            if (streams[r]) { hipSetDevice(devs[r]); hipStreamDestroy(streams[r]); }
+            if (comms[r]) R.CommDestroy(comms[r]);
+        }
+        if (s != IDIST_OK)
+            for (uint32_t i = 0; i < n_devices; i++) { idist_index_free(replicas[i]); replicas[i] = nullptr; }
+        hipSetDevice(root->device);
+        g_err = keep;
+        return s;
+    };
+    // nothing may still be writing the root's buffers (a build on another stream)
+    if (hipSetDevice(root->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        return fail(IDIST_ERR_HIP, "replicate: root device %d: %s", root->device, hipGetErrorString(hipGetLastError()));
+    for (uint32_t i = 0; i < n_devices; i++) {
+        idist_index* r = nullptr;
+        const idist_status st = index_alloc(root->n, root->dim, &root->cfg, root->layer_len, root->n_upper, devices[i], &r);
+        if (st != IDIST_OK) return cleanup(st);
+        replicas[i] = r;
+        r->stats = root->stats;
+        const int rk = (int)(std::find(devs.begin(), devs.end(), (int)devices[i]) - devs.begin());
+        if (first[rk] < 0) first[rk] = (int)i;
+    }
+    int rc = R.CommInitAll(comms.data(), nr, devs.data());
+    if (rc != 0) return cleanup(fail(IDIST_ERR_HIP, "ncclCommInitAll over %d devices: %s", nr, R.GetErrorString(rc)));
+    for (int r = 0; r < nr; r++)
+        if (hipSetDevice(devs[r]) != hipSuccess || hipStreamCreateWithFlags(&streams[r], hipStreamNonBlocking) != hipSuccess)
+            return cleanup(fail(IDIST_ERR_HIP, "replicate: stream on device %d: %s", devs[r], hipGetErrorString(hipGetLastError())));
+    const size_t pb = (size_t)root->n * root->L.stride * 4, zb = (size_t)root->n * IDIST_M2 * 4, ub = root->upper_rows * IDIST_M * 4;
+    struct Buf { const void* src; size_t bytes; int which; };
+    const Buf bufs[3] = {{root->d_points, pb, 0}, {root->d_zero, zb, 1}, {root->d_upper, ub, 2}};
+    auto dst_of = [&](const idist_index* x, int which) -> void* {
+        return which == 0 ? (void*)x->d_points : (which == 1 ? (void*)x->d_zero : (void*)x->d_upper);
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    for (const Buf& b : bufs) {
+        if (!b.bytes) continue;
+        if ((rc = R.GroupStart()) != 0) return cleanup(fail(IDIST_ERR_HIP, "ncclGroupStart: %s", R.GetErrorString(rc)));
+        for (int r = 0; r < nr && rc == 0; r++) {
+            // rank 0 = the root: it sends its own buffer and, if a replica lives on its device, receives into that one
+            void* recv = first[r] >= 0 ? dst_of(replicas[first[r]], b.which) : (void*)b.src;
+            rc = R.Broadcast(b.src, recv, b.bytes, kNcclUint8, 0, comms[r], streams[r]);   // (sendbuff is read on the root only)
+        }
+        const int rc2 = R.GroupEnd();
+        if (rc != 0 || rc2 != 0) return cleanup(fail(IDIST_ERR_HIP, "ncclBroadcast: %s", R.GetErrorString(rc ? rc : rc2)));
+    }
+    for (int r = 0; r < nr; r++)
+        if (hipSetDevice(devs[r]) != hipSuccess || hipStreamSynchronize(streams[r]) != hipSuccess)
+            return cleanup(fail(IDIST_ERR_HIP, "replicate: broadcast to device %d: %s", devs[r], hipGetErrorString(hipGetLastError())));
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // further replicas on a device that already holds one: plain device-to-device copies
+    for (uint32_t i = 0; i < n_devices; i++) {
+        const int rk = (int)(std::find(devs.begin(), devs.end(), (int)devices[i]) - devs.begin());
+        if (first[rk] == (int)i) continue;
+        hipSetDevice(devices[i]);
+        for (const Buf& b : bufs)
+            if (b.bytes && hipMemcpy(dst_of(replicas[i], b.which), dst_of(replicas[first[rk]], b.which), b.bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+                return cleanup(fail(IDIST_ERR_HIP, "replicate: copy on device %d: %s", devices[i], hipGetErrorString(hipGetLastError())));
+    }
+    return cleanup(IDIST_OK);
+#endif
 }
 
 idist_status idist_search_batch_sharded(const idist_index* const* replicas, idist_search_ctx* const* ctxs, uint32_t n_shards,

@@ -42,7 +42,7 @@ constexpr int kTieCap = 64;              // live equidistant candidates kept bey
 constexpr uint32_t kNanBits = 0x7fc00000u;
 constexpr uint64_t kMaxKey = 0x7fffffffffffffffull;
 
-enum : uint32_t { kStTieOverflow = 1u, kStGuard = 2u, kStBadRow = 4u };
+enum : uint32_t { kStTieOverflow = 1u, kStGuard = 2u, kStBadRow = 4u, kStQueue = 8u };
 
 // Device view of an index (plain pointers; lives in kernel arguments).
 struct IndexView {
@@ -1212,7 +1212,9 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     }
 }
 
-struct HeurCounters { uint32_t n_dist, n_rows; };
+// n_dist / n_rows: work as executed here.  n_ref: distance calls as the REFERENCE makes them — `any` stops at the first
+// closer member (core/lib.rs:676-679) — kept by the reference-order kernels only (idist_build_stats.n_heur_ref)
+struct HeurCounters { uint32_t n_dist, n_rows; uint32_t n_ref = 0; };
 
 // ---------------------------------------------------------------------------
 // Search::select_heuristic with extend_candidates = false (core/lib.rs:636-698), selected rows kept on
@@ -1375,6 +1377,7 @@ __device__ __forceinline__ int select_heuristic_tiled(const IndexView& ix, const
                 pruned = cm != 0ull;
                 if (pruned) pr_pid = (uint32_t)sel[b + (__builtin_ctzll(cm) >> 3)];
                 hc.n_dist += (uint32_t)c8;
+                hc.n_ref += pruned ? (uint32_t)(__builtin_ctzll(cm) >> 3) + 1u : (uint32_t)c8;
             }
             for (int b = t.rt; b < nsel && !pruned; b += 8) {        // selected rows that did not fit on chip
                 const int c8 = nsel - b < 8 ? nsel - b : 8;
@@ -1387,6 +1390,7 @@ __device__ __forceinline__ int select_heuristic_tiled(const IndexView& ix, const
                 const uint64_t cm = __ballot(lane < c8 && act_dist[lane] < cd);
                 pruned = cm != 0ull;
                 if (pruned) pr_pid = (uint32_t)sel[b + __builtin_ctzll(cm)];
+                hc.n_ref += pruned ? (uint32_t)__builtin_ctzll(cm) + 1u : (uint32_t)c8;
             }
             if (!pruned) {                                           // :681-684
                 if (lane == 0) sel[nsel] = c;

@@ -196,10 +196,16 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
     for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
     visited_clear(vis);                                                // LDS side; the slot's bitmap is clean between launches
+    bool first_pull = true;
     for (;;) {
         uint32_t qi = 0;
         if (lane == 0) qi = atomicAdd(a.next, 1u) - a.queue_base;
         qi = uniform_u32(qi);
+        // the head counts on from launch to launch: a launch that does not find it inside its own window [queue_base,
+        // queue_base + nq + gridDim.x) was replayed (graph) or interleaved with another launch of the same context —
+        // it would write nothing and the caller would read stale results: say so
+        if (first_pull && qi >= a.nq + gridDim.x) status |= kStQueue;
+        first_pull = false;
         if (qi >= a.nq) break;
 
         // stage the query tile in LDS in the blocked order of the point rows
@@ -393,7 +399,7 @@ struct BuildArgs {
     uint32_t chunk;             // step B: items per dequeue, 0 = by load (IDIST_BUILD_CHUNK, test knob)
     uint32_t tie_cap;           // capacity of the tie region of the descent (idist_config.tie_capacity)
     uint32_t* queue;            // work queue heads: [0] step A, [1] step B, [3] step B2, [4] step A2 ([2] = n_slow)
-    unsigned long long* stats;  // [8] n_dist n_exp0 n_expU n_heur_dist n_heur_rows n_updates
+    unsigned long long* stats;  // [16] n_dist n_exp0 n_expU n_sel_pairs n_heur_rows n_updates n_fast n_full n_heur_ref
     uint32_t* status;
 };
 
@@ -584,6 +590,7 @@ __device__ __forceinline__ int select_extend(const IndexView& ix, const float* q
         dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);                     // :654-657
         wave_sync();
         hc.n_dist += (uint32_t)na;
+        hc.n_ref += (uint32_t)na;
         if (m + (uint32_t)na > work_cap) { status |= kStGuard; break; }
         if (fresh) work[m + (uint32_t)my] = ((uint64_t)act_dist[my] << 32) | nb;
         m += (uint32_t)na;
@@ -610,7 +617,9 @@ __device__ __forceinline__ int select_extend(const IndexView& ix, const float* q
             dist_rounds<NB, RS, TAIL>(ix, q2, act_pid, act_dist, nsel);              // :676-679
             wave_sync();
             hc.n_dist += (uint32_t)nsel;
-            pruned = __ballot(lane < nsel && act_dist[lane] < cd) != 0ull;           // OrderedFloat order == order of the canonical bits
+            const uint64_t cm = __ballot(lane < nsel && act_dist[lane] < cd);        // OrderedFloat order == order of the canonical bits
+            pruned = cm != 0ull;
+            hc.n_ref += pruned ? (uint32_t)__builtin_ctzll(cm) + 1u : (uint32_t)nsel;  // `any` stops at the first closer member
         }
         wave_sync();
         if (!pruned) {                                                               // :681-684
@@ -685,6 +694,7 @@ __global__ __launch_bounds__(64) void build_extend_kernel(IndexView ix, BuildArg
         dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, 1);
         wave_sync();
         hc.n_dist += 1u;
+        hc.n_ref += 1u;
         w_push_keys(ns, lane == 0 ? (((uint64_t)sm.act_dist[0] << 32) | nw_pid) : kMaxKey, lane == 0);   // :626
         bool fresh = false;
         int tab_idx = -1;
@@ -704,8 +714,10 @@ __global__ __launch_bounds__(64) void build_extend_kernel(IndexView ix, BuildArg
             dist_rounds<NB, RS, TAIL>(ix, sm.q, sm.act_pid, sm.act_dist, na);
             wave_sync();
             hc.n_dist += (uint32_t)na;
+            hc.n_ref += (uint32_t)na;
             w_push_keys(ns, fresh ? (((uint64_t)sm.act_dist[my] << 32) | cur) : kMaxKey, fresh);
         }
+        status |= ns.status;                                                         // a tie overflow of the re-selection's own list
         const int nres = select_extend<NB, RS, TAIL>(ix, sm.q, q2, W2, ns.plen, vis, work, work_cap, a.keep_pruned != 0, sel, disc,
                                                      sm.act_pid, sm.act_dist, hc, status);       // :630
         ix.zero[(size_t)pid * kM2 + lane] = lane < nres ? (uint32_t)sel[lane] : kInvalid;        // ZeroNode::rewrite, :495
@@ -722,6 +734,7 @@ __global__ __launch_bounds__(64) void build_extend_kernel(IndexView ix, BuildArg
         atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
         atomicAdd(&a.stats[5], (unsigned long long)nf);
         atomicAdd(&a.stats[7], (unsigned long long)nf);
+        atomicAdd(&a.stats[8], (unsigned long long)hc.n_ref);
     }
 }
 
@@ -775,6 +788,7 @@ __global__ __launch_bounds__(64) void build_select_kernel(IndexView ix, BuildArg
     if (lane == 0 && (hc.n_dist | hc.n_rows)) {
         atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
         atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);
+        atomicAdd(&a.stats[8], (unsigned long long)hc.n_ref);
     }
 }
 
@@ -1315,6 +1329,7 @@ __global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArg
                 if (idx < st.ef) w_insert(st, idx, k);
             }
         }
+        hc.n_ref += (uint32_t)(k_new + ncur);                           // the pushes of :626-629: one distance call each
         // select_heuristic over ALL of `nearest` (no truncate in add_neighbor_heuristic, :630)
         int n_selected = 0;
         const int nsel = select_heuristic_tiled<NB, RS, TAIL>(ix, st.W, st.plen, a.keep_pruned != 0, tile, sel, disc,
@@ -1334,6 +1349,7 @@ __global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArg
             atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);
             atomicAdd(&a.stats[5], (unsigned long long)updates);
             atomicAdd(&a.stats[7], (unsigned long long)updates);
+            atomicAdd(&a.stats[8], (unsigned long long)hc.n_ref);
         }
     }
 }

@@ -70,6 +70,9 @@ extern "C" {
                           out_counters: *mut u32) -> i32;
     // several GPUs of one node: replicate once, shard the queries of a batch
     fn idist_replicate(root: *const IdistIndex, devices: *const i32, n_devices: u32, replicas: *mut *mut IdistIndex) -> i32;
+    // the same as one RCCL broadcast per buffer (ncclCommInitAll over the devices, inside libidist)
+    fn idist_replicate_rccl(root: *const IdistIndex, devices: *const i32, n_devices: u32, replicas: *mut *mut IdistIndex,
+                            seconds: *mut f64) -> i32;
     fn idist_search_batch_sharded(replicas: *const *const IdistIndex, ctxs: *const *mut IdistSearchCtx, n_devices: u32,
                                   queries: *const f32, nq: u32, out_pid: *mut u32, out_dist: *mut f32,
                                   out_count: *mut u32, out_counters: *mut u32) -> i32;
@@ -114,8 +117,10 @@ unsafe impl Send for GpuIndex {}
 impl Drop for GpuIndex { fn drop(&mut self) { unsafe { idist_index_free(self.idx) } } }
 
 /// `#[serde(skip)] gpu: gpu::Cache` in `struct Hnsw`: `None` inside = this point type / machine has no GPU path.
+/// The second field is the device the index lives on / is re-imported onto: `Builder::device` for an index built here,
+/// `Hnsw::on_device` for one that came out of `serde` (0 until then).
 #[derive(Default)]
-pub(crate) struct Cache(OnceLock<Option<GpuIndex>>);
+pub(crate) struct Cache(OnceLock<Option<GpuIndex>>, std::sync::atomic::AtomicI32);
 
 fn config(b: &Builder, metric: Metric) -> IdistConfig {
     let mut cfg = unsafe { std::mem::zeroed::<IdistConfig>() };
@@ -179,11 +184,14 @@ pub(crate) fn try_build<P: Point>(points: &[P], b: &Builder) -> Option<(Vec<Zero
     }).collect();
     let layers = upper_raw.iter().map(|raw| raw.chunks_exact(M).map(UpperNode::from_ids).collect()).collect();   // from_ids: 3-line helper in the patch
     let cache = Cache::default();
+    cache.1.store(b.device, Ordering::Relaxed);                       // a later re-import (never needed for this object) would land here too
     let _ = cache.0.set(Some(GpuIndex::new(idx, dim)));
     Some((zero, layers, cache))
 }
 
 impl Cache {
+    /// `Hnsw::on_device`: where a deserialised index is imported on its first search (no effect once it is on a device)
+    pub(crate) fn set_device(&self, device: i32) { self.1.store(device, Ordering::Relaxed); }
     /// The device index of `hnsw`, imported from its own fields on first use (after `serde` deserialisation,
     /// or for an index built by the CPU code on a machine that now has a GPU).
     pub(crate) fn get<P: Point>(&self, ef_search: usize, points: &[P], zero: &[ZeroNode], layers: &[Vec<UpperNode>]) -> Option<&GpuIndex> {
@@ -199,8 +207,9 @@ impl Cache {
             let ptrs: Vec<*const u32> = upper_raw.iter().map(|v| v.as_ptr()).collect();
             let lens: Vec<u32> = layers.iter().map(|l| l.len() as u32).collect();
             let mut idx = std::ptr::null_mut();
+            let device = self.1.load(Ordering::Relaxed);                 // Builder::device / Hnsw::on_device, not "GPU 0"
             expect(unsafe { idist_index_import(flat.as_ptr(), points.len() as u32, dim as u32, &cfg, zero_raw.as_ptr(),
-                                               ptrs.as_ptr(), lens.as_ptr(), lens.len() as u32, 0, &mut idx) });
+                                               ptrs.as_ptr(), lens.as_ptr(), lens.len() as u32, device, &mut idx) });
             Some(GpuIndex::new(idx, dim))
         }).as_ref()
     }
@@ -271,7 +280,9 @@ impl Drop for Replicas {
 impl Replicas {
     pub(crate) fn new(root: &GpuIndex, devices: &[i32], ef: usize) -> Self {
         let mut idx = vec![std::ptr::null_mut(); devices.len()];
-        expect(unsafe { idist_replicate(root.idx, devices.as_ptr(), devices.len() as u32, idx.as_mut_ptr()) });
+        // RCCL broadcast over xGMI; a machine without librccl (status 4) gets the peer-copy flavour
+        let st = unsafe { idist_replicate_rccl(root.idx, devices.as_ptr(), devices.len() as u32, idx.as_mut_ptr(), std::ptr::null_mut()) };
+        if st == 4 { expect(unsafe { idist_replicate(root.idx, devices.as_ptr(), devices.len() as u32, idx.as_mut_ptr()) }); } else { expect(st); }
         let ctx = idx.iter().map(|&i| { let mut c = std::ptr::null_mut(); expect(unsafe { idist_search_ctx_new(i, 0, &mut c) }); c }).collect();
         Self { idx, ctx, dim: root.dim, ef }
     }

@@ -415,6 +415,7 @@ struct ido_index {
     uint32_t n_upper;     /* layers.len() */
     uint32_t** layers;    /* layers[l-1] : layer_len[l-1]*32 */
     uint32_t* layer_len;
+    int borrowed;         /* points / zero belong to the caller (ido_import_borrowed) */
 };
 
 void ido_default_config(ido_config* c) { /* core/lib.rs:101-128 */
@@ -763,13 +764,39 @@ ido_index* ido_import(const float* points, uint32_t n, uint32_t dim, const ido_c
     return ix;
 }
 
+/* The same index over the CALLER's points / zero arrays (no copy: a 10M x 768 index is 31 GB of points); the caller
+ * keeps them alive and unchanged for the life of the handle.  Search only. */
+ido_index* ido_import_borrowed(const float* points, uint32_t n, uint32_t dim, const ido_config* cfg,
+                               const uint32_t* zero, const uint32_t* const* layers,
+                               const uint32_t* layer_len, uint32_t n_upper) {
+    ido_index* ix = (ido_index*)calloc(1, sizeof(*ix));
+    ix->cfg = *cfg;
+    ix->n = n;
+    ix->dim = dim;
+    ix->borrowed = 1;
+    ix->points = (float*)points;
+    ix->zero = (uint32_t*)zero;
+    ix->n_upper = n_upper;
+    ix->layers = (uint32_t**)calloc(n_upper ? n_upper : 1, sizeof(uint32_t*));
+    ix->layer_len = (uint32_t*)calloc(n_upper ? n_upper : 1, sizeof(uint32_t));
+    for (uint32_t l = 0; l < n_upper; l++) {
+        size_t bytes = (size_t)layer_len[l] * IDO_M * sizeof(uint32_t);
+        ix->layers[l] = (uint32_t*)malloc(bytes ? bytes : 1);
+        memcpy(ix->layers[l], layers[l], bytes);
+        ix->layer_len[l] = layer_len[l];
+    }
+    return ix;
+}
+
 void ido_free(ido_index* ix) {
     if (!ix) return;
     for (uint32_t l = 0; l < ix->n_upper; l++) free(ix->layers[l]);
     free(ix->layers);
     free(ix->layer_len);
-    free(ix->zero);
-    free(ix->points);
+    if (!ix->borrowed) {
+        free(ix->zero);
+        free(ix->points);
+    }
     free(ix);
 }
 

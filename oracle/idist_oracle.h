@@ -88,6 +88,11 @@ ido_index* ido_import(const float* points, uint32_t n, uint32_t dim,
                       const ido_config* cfg, const uint32_t* zero,
                       const uint32_t* const* layers, const uint32_t* layer_len,
                       uint32_t n_upper);
+/* the same over the caller's points / zero arrays (no copy; search only; the caller keeps them alive) */
+ido_index* ido_import_borrowed(const float* points, uint32_t n, uint32_t dim,
+                      const ido_config* cfg, const uint32_t* zero,
+                      const uint32_t* const* layers, const uint32_t* layer_len,
+                      uint32_t n_upper);
 void ido_free(ido_index*);
 
 uint32_t ido_n(const ido_index*);

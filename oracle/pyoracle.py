@@ -74,6 +74,8 @@ def lib():
         L.ido_import.restype = C.c_void_p
         L.ido_import.argtypes = [f32p, C.c_uint32, C.c_uint32, C.POINTER(Config), u32p,
                                  C.POINTER(u32p), u32p, C.c_uint32]
+        L.ido_import_borrowed.restype = C.c_void_p
+        L.ido_import_borrowed.argtypes = L.ido_import.argtypes
         L.ido_free.argtypes = [C.c_void_p]
         for name in ("ido_n", "ido_dim", "ido_n_upper"):
             getattr(L, name).restype = C.c_uint32
@@ -170,7 +172,9 @@ class Index:
         return ix
 
     @classmethod
-    def from_arrays(cls, points, zero, layers, cfg: Config | None = None):
+    def from_arrays(cls, points, zero, layers, cfg: Config | None = None, borrow: bool = False):
+        """borrow=True: the index reads `points` / `zero` in place (they must be C-contiguous f32 / u32 and are kept
+        alive by the returned object) — for indexes whose points would not fit in host memory twice."""
         cfg = cfg or default_config()
         pts = np.ascontiguousarray(points, dtype=np.float32)
         n, dim = pts.shape
@@ -178,8 +182,12 @@ class Index:
         layers = [np.ascontiguousarray(l, dtype=np.uint32).reshape(-1, M) for l in layers]
         ptrs = (C.POINTER(C.c_uint32) * max(len(layers), 1))(*[_u32(l) for l in layers])
         lens = np.array([l.shape[0] for l in layers] + [0], dtype=np.uint32)
-        h = lib().ido_import(_f32(pts), n, dim, C.byref(cfg), _u32(zero), ptrs, _u32(lens), len(layers))
-        return cls(h, cfg)
+        fn = lib().ido_import_borrowed if borrow else lib().ido_import
+        h = fn(_f32(pts), n, dim, C.byref(cfg), _u32(zero), ptrs, _u32(lens), len(layers))
+        ix = cls(h, cfg)
+        if borrow:
+            ix._keep = (pts, zero)
+        return ix
 
     @property
     def n(self):

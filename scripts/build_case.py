@@ -12,4 +12,4 @@ n, dim = 1_000_000, int(os.environ.get("BC_DIM", 300))
 pts = gen(np.random.default_rng(123456789), n, dim, "lowrank")
 h = ida.Hnsw.from_ordered_points(pts, ida.Builder())
 st = h.build_stats()
-print("build_s", st.seconds, "n_heur_dist", st.n_heur_dist)
+print("build_s", st.seconds, "n_sel_pairs", st.n_sel_pairs)

@@ -50,7 +50,7 @@ for env, nm in cases:
     got = h.search_batch(q, ida.Search())
     rec = float(np.mean([len(set(got.pid[i, :10].tolist()) & set(truth[i].tolist())) / 10 for i in range(len(q))]))
     emit(case=nm, env=env, seconds=round(st.seconds, 4), points_per_s=round(n / st.seconds), recall_at_10=round(rec, 4),
-         n_dist=int(st.n_dist), n_heur_dist=int(st.n_heur_dist), n_heur_rows=int(st.n_heur_rows), n_updates=int(st.n_updates),
+         n_dist=int(st.n_dist), n_sel_pairs=int(st.n_sel_pairs), n_heur_rows=int(st.n_heur_rows), n_updates=int(st.n_updates),
          n_updates_full=int(st.n_updates_full), batches=int(st.n_batches))
     for k in env:
         os.environ.pop(k)

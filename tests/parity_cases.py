@@ -31,7 +31,10 @@ SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by
                    ("bitmap classic", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "0", "IDIST_WALK": "classic"}))
 # The descent of an insertion shares the walk code; what varies there is the walk mode (classic / overlap) and the size
 # of the on-chip visited set — it never runs four waves per item and has no bitmap-only variant.
+# (the third field: the variant runs every selection in the reference's own order, so its count of distance calls inside
+#  select_heuristic / add_neighbor_heuristic must equal the oracle's n_heur)
 BUILD_VARIANTS = (("on-chip", {}),
+                  ("reference-order kernels: LDS-tile selection, every update from scratch", {"IDIST_BUILD_A2": "tile", "IDIST_BUILD_NO_FAST": "1"}),
                   ("step A2 with the LDS-tile kernel instead of the Gram matrix on MFMA", {"IDIST_BUILD_A2": "tile"}),
                   ("on-chip classic", {"IDIST_WALK": "classic"}),
                   ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7"}),
@@ -43,7 +46,7 @@ def search_variant(env):
     if isinstance(env, str):                     # a bare IDIST_LATENCY_NQ value
         env = {"IDIST_LATENCY_NQ": env}
     keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ", "IDIST_BUILD_A2",
-            "IDIST_TAB_FORMAT")
+            "IDIST_TAB_FORMAT", "IDIST_BUILD_NO_FAST")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)
@@ -162,6 +165,12 @@ def check_build_exact(ida, oracle, n, dim, metric=0, kind="uniform", ef_construc
         st = h.build_stats()
         assert st.n_dist == oix.build_counters.n_dist
         assert st.n_exp0 == oix.build_counters.n_exp0 and st.n_expU == oix.build_counters.n_expU
+        # the reference's own count of distance calls inside select_heuristic + add_neighbor_heuristic (early-exit `any`,
+        # core/lib.rs:676-679): defined where every selection ran in the reference's order
+        if heuristic and (extend or (max_batch == 1 and "IDIST_BUILD_NO_FAST" in lat and lat.get("IDIST_BUILD_A2") == "tile")):
+            assert st.n_heur_ref == oix.build_counters.n_heur, (st.n_heur_ref, oix.build_counters.n_heur)
+        elif not extend:
+            assert st.n_heur_ref == 0
     return h
 
 

@@ -626,23 +626,6 @@ def test_tie_policy(eng, oracle):
     assert np.array_equal(a.into_parts()[0], b.into_parts()[0]) and b.build_stats().tie_overflow == 0
 
 
-def test_index_rehome_keeps_results(eng, oracle):
-    """idist_index_rehome moves the device buffers; contexts stay valid and results do not change."""
-    ida, kind = eng
-    pts, oix, _ = pc.oracle_graph(oracle, S(kind, 200, 70000), S(kind, 7, 32), "uniform", 0, 51, 1, 100)
-    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder())
-    q = pc.gen_points(np.random.default_rng(52), S(kind, 5, 3000), pts.shape[1])
-    s = ida.Search()
-    a = h.search_batch(q, s, counters=True)
-    for _ in range(3):
-        h.rehome()
-        b = h.search_batch(q, s, counters=True)
-        assert np.array_equal(a.pid, b.pid) and np.array_equal(pc.bits(a.distance), pc.bits(b.distance))
-        assert np.array_equal(a.counters, b.counters)
-    z0, l0 = h.into_parts()
-    assert np.array_equal(z0, oix.zero) and all(np.array_equal(x, y) for x, y in zip(l0, oix.layers))
-
-
 def test_strict_ties_enlarge_the_region_on_demand(eng, oracle):
     """The escalation machinery on data small enough for the oracle: with a deliberately tiny tie region (1 entry)
     integer-grid data overflows it at once; STRICT must still end with the reference's results (search batch searched

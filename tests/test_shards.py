@@ -37,12 +37,17 @@ def test_replicate_and_sharded_search_match_single_gpu_and_oracle(eng, oracle):
     single = h.search_batch(q, ida.Search(), counters=True)
     pc.check_search_result(single, want)
     devices = list(range(_capi.lib().device_count())) + [0]          # every GPU there is, plus a second copy on GPU 0
-    reps = h.replicate(devices)
-    assert len(reps) == len(devices)
-    for r, d in zip(reps, devices):
-        assert r.info().device == d and r.info().n == n
-        z, layers = r.into_parts()
-        assert np.array_equal(z, oix.zero) and all(np.array_equal(a, b) for a, b in zip(layers, oix.layers))
+    for rccl in (True, False):                                        # one RCCL broadcast per buffer / peer copies from the root
+        reps = h.replicate(devices, rccl=rccl)
+        assert len(reps) == len(devices)
+        for r, d in zip(reps, devices):
+            assert r.info().device == d and r.info().n == n
+            z, layers = r.into_parts()
+            assert np.array_equal(z, oix.zero) and all(np.array_equal(a, b) for a, b in zip(layers, oix.layers))
+            # the point rows travelled too: the replica answers like the root, bit for bit
+            pc.check_search_result(r.search_batch(q[:16], ida.Search(), counters=True), oix.search(q[:16]))
+        if rccl:
+            assert h.last_replicate_seconds >= 0.0
     for shards in (reps, reps[:1], [h] + reps):                      # any mix of replicas (the root is one too)
         got = ida.Hnsw.search_batch_sharded(shards, [ida.Search() for _ in shards], q, counters=True)
         pc.check_search_result(got, want)
@@ -117,6 +122,9 @@ def test_search_scratch_grows_on_demand(eng, oracle):
     for slots in (1, 2, 5):                                           # fixed slot counts: fewer slots than queries
         got = h.search_batch(q, ida.Search(slots), counters=True)
         pc.check_search_result(got, want)
+    s2 = ida.Search()                                                 # Vec::reserve on the scratch: backed up front, same answers
+    s2.reserve(h, len(q))
+    pc.check_search_result(h.search_batch(q, s2, counters=True), want)
 
 
 def test_narrow_host_batches_zero_copy_equals_staged(eng, oracle, monkeypatch):
