@@ -373,7 +373,14 @@ def main():
             del outs2, srt
 
         cpu, parity = None, None
-        if not args.no_cpu_baseline and world == 1:
+        need_gb = (n * dim * 4 + n * 256 * 2) / 2**30 + 4
+        try:
+            avail_gb = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) / 2**20
+        except Exception:  # noqa: BLE001
+            avail_gb = 1e9
+        if not args.no_cpu_baseline and world == 1 and avail_gb < need_gb:
+            parity = {"skipped": f"the oracle needs the points on the host: {need_gb:.0f} GB, {avail_gb:.0f} GB available"}
+        elif not args.no_cpu_baseline and world == 1:
             from oracle import pyoracle as po
             zero, layers = hnsw.into_parts()
             if checks is not None:
