@@ -170,6 +170,7 @@ struct Knobs {
     uint32_t tab_log2 = 0;        // IDIST_TAB_LOG2=<5..13>: size of the on-chip visited set (test knob: small sets exercise the overflow path)
     bool vis_bitmap = false;      // IDIST_VISITED=bitmap: search with bitmap + Bloom filter (16 waves per CU) instead of the on-chip set
     bool vis_onchip = false;      // IDIST_VISITED=onchip: the on-chip set whatever the policy says (test / A-B knob)
+    bool events = true;           // IDIST_KERNEL_EVENTS=0: no HIP events around the search kernels (idist_search_ctx_kernel_times then has nothing)
     bool tab_ids = false;         // IDIST_TAB_FORMAT=ids: the on-chip set of a search keeps full ids (4 per bucket, frozen at 7/8) instead of
                                   // 16-bit quotients (8 per bucket, single ids overflow) (test / A-B knob)
     bool no_zero_copy = false;    // IDIST_NO_ZERO_COPY=1: narrow host-pointer batches take the general (staged) path too (test / A-B knob)
@@ -186,6 +187,7 @@ struct Knobs {
         if (const char* e = getenv("IDIST_VISITED")) { k.vis_bitmap = e[0] == 'b'; k.vis_onchip = e[0] == 'o'; }
         if (const char* e = getenv("IDIST_NO_ZERO_COPY")) k.no_zero_copy = e[0] != '0';
         if (const char* e = getenv("IDIST_TAB_FORMAT")) k.tab_ids = e[0] == 'i';
+        if (const char* e = getenv("IDIST_KERNEL_EVENTS")) k.events = e[0] != '0';
         if (const char* e = getenv("IDIST_TAB_LOG2")) k.tab_log2 = std::min(13u, std::max(5u, (uint32_t)atoi(e)));
         return k;
     }
@@ -347,20 +349,36 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     // core/lib.rs:649 vs :438), one whole insertion per launch in program order — always the sequential schedule
     const bool ext = cfg.has_heuristic && cfg.extend_candidates;
     const uint32_t cap = ext ? 1u : std::min<uint32_t>(cfg.max_batch == 0 ? 8192u : cfg.max_batch, std::max<uint32_t>(1u, n / 32u));
-    // the descents keep their visited set on chip, one wave per SIMD (4 per CU), like the search walk
-    const uint32_t slots = std::min(cap, (uint32_t)ix->n_cu * 4u);
+    // the descents keep their visited set on chip, one fat wave per SIMD (up to 8 per CU with the 16-KB quotient set)
+    const uint32_t slots = std::min(cap, (uint32_t)ix->n_cu * 8u);
     const VisGeom vg = vis_geometry(n);
     const Knobs knobs = Knobs::from_env();
     const uint32_t tie_cap = tie_capacity(cfg);
     const uint32_t wcap = cfg.ef_construction + 64 + tie_cap + 64;
-    // the largest on-chip set that leaves room for four waves per CU; if W alone is too big for that, the largest that fits at all
+    // The descents' on-chip visited set.  Quotient form (16-bit entries, idist_device.hpp q16_*) where n allows it: 16 KB hold
+    // 8192 ids — an ef_construction = 100 descent visits ~6k — so a descent wave takes ~22 KB of LDS instead of ~39 KB
+    // and four or five of them leave half the CU's LDS to the update stream.  Otherwise (and IDIST_TAB_FORMAT=ids, ext):
+    // full ids, the largest set that leaves room for four waves per CU, or the largest that fits at all.
     uint32_t tab_log2 = 0;
-    for (uint32_t l = 13; l >= 8 && !tab_log2; l--)
-        if (smem_bytes(ix->L.stride, wcap, true, 1u << l, vg.dirty_words) <= kOnChipLdsPerWave) tab_log2 = l;
-    for (uint32_t l = 13; l >= 8 && !tab_log2; l--)
-        if (smem_bytes(ix->L.stride, wcap, true, 1u << l, vg.dirty_words) <= 64 * 1024) tab_log2 = l;
-    if (!tab_log2) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need more than 64 KiB of LDS per wave");
-    if (knobs.tab_log2) tab_log2 = std::max(8u, std::min(tab_log2, knobs.tab_log2));
+    bool tab16 = false;
+    if (!ext && !knobs.tab_ids) {
+        const uint32_t want = knobs.tab_log2 ? std::max(8u, std::min(13u, knobs.tab_log2))
+                                             : (cfg.ef_construction <= 128 ? 12u : 13u);
+        for (uint32_t l = want; l <= 13 && !tab16; l++)
+            if (q16_applies(l, q16_universe_bits(n, l)) && smem_bytes(ix->L.stride, wcap, true, 1u << l, vg.dirty_words) <= kOnChipLdsPerWave) {
+                tab_log2 = l;
+                tab16 = true;
+            }
+    }
+    if (!tab16) {
+        for (uint32_t l = 13; l >= 8 && !tab_log2; l--)
+            if (smem_bytes(ix->L.stride, wcap, true, 1u << l, vg.dirty_words) <= kOnChipLdsPerWave) tab_log2 = l;
+        for (uint32_t l = 13; l >= 8 && !tab_log2; l--)
+            if (smem_bytes(ix->L.stride, wcap, true, 1u << l, vg.dirty_words) <= 64 * 1024) tab_log2 = l;
+        if (!tab_log2) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need more than 64 KiB of LDS per wave");
+        if (knobs.tab_log2) tab_log2 = std::max(8u, std::min(tab_log2, knobs.tab_log2));
+    }
+    const uint32_t dl_shift = tab_log2 + (tab16 ? 1u : 0u);
     const size_t smem = smem_bytes(ix->L.stride, wcap, true, 1u << tab_log2, vg.dirty_words);
 
     // step B tile: as many selected rows on chip as fit 64 KiB of LDS next to 8 staging slots
@@ -408,8 +426,13 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     bool pipe = cap > 1 && cfg.has_heuristic;
     if (const char* e = getenv("IDIST_BUILD_PIPELINE")) pipe = pipe && e[0] != '0';
     // the descents (8-12 waves per CU saturate their HBM stream) leave wave slots and LDS to the other stream
-    uint32_t a_waves = 3;
-    if (const char* e = getenv("IDIST_BUILD_A_WAVES")) a_waves = std::min(4, std::max(1, atoi(e)));
+    uint32_t a_waves = tab16 ? 4u : 3u;
+    if (const char* e = getenv("IDIST_BUILD_A_WAVES")) a_waves = (uint32_t)std::min(8, std::max(1, atoi(e)));
+    bool a_regs256 = false;               // IDIST_BUILD_A_REGS=256: the two-waves-per-SIMD instantiation of the descent (quotient set only)
+    if (const char* e = getenv("IDIST_BUILD_A_REGS")) a_regs256 = atoi(e) == 256;
+    // what one CU's LDS holds of them (the sequential schedule runs nothing beside the descents)
+    const uint32_t a_waves_max = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)((160u * 1024u) / smem)));
+    a_waves = std::min(a_waves, a_waves_max);
     uint32_t* d_zero2 = nullptr;
     hipStream_t s1 = nullptr, s2 = nullptr;
     hipEvent_t evA[2] = {nullptr, nullptr}, evS[2] = {nullptr, nullptr};
@@ -446,7 +469,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     const size_t np = pipe ? 2 : 1;       // step-A outputs are double-buffered in the pipelined schedule
     BCHK(hipMalloc((void**)&d_wbuf, np * cap * cfg.ef_construction * 8));
     BCHK(hipMalloc((void**)&d_wcount, np * cap * 4));
-    const size_t dl_n = cfg.has_heuristic ? (np * cap) << tab_log2 : 64;   // the simple splice looks nothing up
+    const size_t dl_n = cfg.has_heuristic ? (np * cap) << dl_shift : 64;   // the simple splice looks nothing up
     BCHK(hipMalloc((void**)&d_dlog_log, dl_n * 8));
     BCHK(hipMalloc((void**)&d_dlog_pd, dl_n * 8));
     if (pipe) {
@@ -496,6 +519,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     a.dlog_log = d_dlog_log;
     a.dlog_pd = d_dlog_pd;
     a.tab_log2 = tab_log2;
+    a.tab16 = tab16 ? 1u : 0u;
+    a.ubits = tab16 ? q16_universe_bits(n, tab_log2) : 0u;
+    a.dl_shift = dl_shift;
     a.use_dlog = getenv("IDIST_BUILD_NO_DLOG") ? 0u : 1u;
     a.wbuf = d_wbuf;
     a.wcount = d_wcount;
@@ -550,15 +576,15 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
                 viewA.zero = zbuf[(k - lag) & 1u];
                 viewS.zero = zbuf[par];
                 aA.queue = d_small + 1;
-                aA.dlog_log = d_dlog_log + (((size_t)par * cap) << tab_log2);
-                aA.dlog_pd = d_dlog_pd + (((size_t)par * cap) << (tab_log2 + 1u));
+                aA.dlog_log = d_dlog_log + (((size_t)par * cap) << dl_shift);
+                aA.dlog_pd = d_dlog_pd + (((size_t)par * cap) << (dl_shift + 1u));
                 aA.wbuf = d_wbuf + (size_t)par * cap * cfg.ef_construction;
                 aA.wcount = d_wcount + (size_t)par * cap;
                 BCHK(hipMemsetAsync(d_small, 0, 8, sA));                  // step A queue head
             } else {
                 BCHK(hipMemsetAsync(d_small, 0, 24, sA));                 // n_touched, queue heads, n_slow
             }
-            const uint32_t gridA = std::min(B, pipe ? std::min<uint32_t>(slots, (uint32_t)ix->n_cu * a_waves) : slots);
+            const uint32_t gridA = std::min(B, std::min<uint32_t>(slots, (uint32_t)ix->n_cu * (pipe ? a_waves : std::min(a_waves_max, a_regs256 ? 8u : 4u))));
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
             const uint32_t gridS = std::min<uint32_t>(gridB, (uint32_t)ix->n_cu * 6);
             const uint32_t gridA2 = std::min<uint32_t>(B, (uint32_t)ix->n_cu * 4);
@@ -572,6 +598,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     {                                                                                              \
         auto kA = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>; \
         auto kAo = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true)>; \
+        auto kA16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true, false, true)>; \
+        auto kAo16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
+        /* two descent waves per SIMD: 256 registers each, fewer rounds in flight per wave, more waves */ \
+        auto kAo16w2 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 2 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
         auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
@@ -579,6 +609,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         auto kX = build_extend_kernel<NB_, RS_, TAIL_>;                                            \
         auto kA2m = build_select_mfma_kernel<NB_, RS_, TAIL_>;                                     \
         if (ext) { IDIST_LAUNCH(kX, 1, 64, smemX, sA, viewA, aA, d_ext_work, ext_cap); }           \
+        else if (classic && tab16) { IDIST_LAUNCH(kA16, gridA, 64, smem, sA, viewA, aA); }         \
+        else if (tab16 && a_regs256) { IDIST_LAUNCH(kAo16w2, gridA, 64, smem, sA, viewA, aA); }    \
+        else if (tab16) { IDIST_LAUNCH(kAo16, gridA, 64, smem, sA, viewA, aA); }                   \
         else if (classic) { IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA); }                    \
         else { IDIST_LAUNCH(kAo, gridA, 64, smem, sA, viewA, aA); }                                \
         if (pipe) {                                                                                \
@@ -791,7 +824,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     a.status_host = status_host && grid <= idist_search_ctx::kIoStatusSlots ? status_host : nullptr;
     if (grid_out) *grid_out = grid;
     const uint32_t slot = (uint32_t)(ctx->n_launch % IDIST_EVENT_RING);
-    HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
+    if (ctx->knobs.events) HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
 #define LAUNCH_SEARCH(NB_, RS_, TAIL_)                                                             \
     {                                                                                              \
         if (quad && q16) {                                                                         \
@@ -863,8 +896,10 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
         return fail(IDIST_ERR_HIP, "search launch failed: %s", hipGetErrorString(le));
     }
     ctx->queue_base += nq + grid;
-    HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
-    ctx->n_launch++;
+    if (ctx->knobs.events) {
+        HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
+        ctx->n_launch++;
+    }
     return IDIST_OK;
 }
 

@@ -645,12 +645,13 @@ __device__ __forceinline__ int tab_insert(const Visited& v, uint32_t pid) {
 // ---------------------------------------------------------------------------
 enum : int { kQFound = 0, kQRoom = 1, kQFull = 2 };
 struct Q16Keys { uint32_t b1, t1, b2, t2; };
-__device__ __forceinline__ Q16Keys q16_keys(const Visited& v, uint32_t pid) {
-    const uint32_t um = (1u << v.ubits) - 1u, rm = (1u << v.rbits) - 1u;
+__device__ __forceinline__ Q16Keys q16_keys(uint32_t ubits, uint32_t rbits, uint32_t pid) {
+    const uint32_t um = (1u << ubits) - 1u, rm = (1u << rbits) - 1u;
     const uint32_t h1 = (pid * 0x9E3779B1u) & um;
     const uint32_t h2 = ((pid ^ (pid >> 7)) * 0x85EBCA6Bu + 0xC2B2AE35u) & um;
-    return Q16Keys{h1 >> v.rbits, h1 & rm, h2 >> v.rbits, (h2 & rm) | (1u << v.rbits)};
+    return Q16Keys{h1 >> rbits, h1 & rm, h2 >> rbits, (h2 & rm) | (1u << rbits)};
 }
+__device__ __forceinline__ Q16Keys q16_keys(const Visited& v, uint32_t pid) { return q16_keys(v.ubits, v.rbits, pid); }
 __device__ __forceinline__ bool q16_word_has(uint32_t w, uint32_t tt) {     // tt = t | t << 16
     const uint32_t x = w ^ tt;
     return (x & 0xFFFFu) == 0u || (x >> 16) == 0u;
@@ -671,9 +672,26 @@ __device__ __forceinline__ int q16_lookup(const Visited& v, uint32_t pid) {
     if (q16_has(e1, k.t1) || q16_has(e2, k.t2)) return kQFound;
     return ((e1.w >> 16) == 0xFFFFu || (e2.w >> 16) == 0xFFFFu) ? kQRoom : kQFull;
 }
-// insert: kQRoom = it went in, kQFound = it was there, kQFull = both home buckets are full (the caller uses the bitmap).
-// Lanes of a wave insert distinct ids concurrently; the loser of a race for a word looks again.
-__device__ __forceinline__ int q16_insert(const Visited& v, uint32_t pid) {
+// slot (0..7) of the entry t in a bucket, -1 if it is not there
+__device__ __forceinline__ int q16_slot(const uint4 e, uint32_t t) {
+    auto ws = [t](uint32_t w) { return (w & 0xFFFFu) == t ? 0 : ((w >> 16) == t ? 1 : -1); };
+    const int a = ws(e.x), b = ws(e.y), c = ws(e.z), d = ws(e.w);
+    return a >= 0 ? a : (b >= 0 ? 2 + b : (c >= 0 ? 4 + c : (d >= 0 ? 6 + d : -1)));
+}
+// index of pid in the set = 8 * bucket + slot, -1 if it is not there (ids that overflowed to the bitmap have none)
+__device__ __forceinline__ int q16_index(const Visited& v, uint32_t pid) {
+    const Q16Keys k = q16_keys(v, pid);
+    const uint4 e1 = *reinterpret_cast<const uint4*>(v.tab + 4u * k.b1);
+    const uint4 e2 = *reinterpret_cast<const uint4*>(v.tab + 4u * k.b2);
+    const int s1 = q16_slot(e1, k.t1);
+    if (s1 >= 0) return (int)(8u * k.b1) + s1;
+    const int s2 = q16_slot(e2, k.t2);
+    return s2 >= 0 ? (int)(8u * k.b2) + s2 : -1;
+}
+// insert: kQRoom = it went in (idx = where), kQFound = it was there, kQFull = both home buckets are full (the caller
+// uses the bitmap).  Lanes of a wave insert distinct ids concurrently; the loser of a race for a word looks again.
+__device__ __forceinline__ int q16_insert(const Visited& v, uint32_t pid, int& idx) {
+    idx = -1;
     const Q16Keys k = q16_keys(v, pid);
     for (;;) {
         const uint4 e1 = *reinterpret_cast<const uint4*>(v.tab + 4u * k.b1);
@@ -688,8 +706,16 @@ __device__ __forceinline__ int q16_insert(const Visited& v, uint32_t pid) {
         const int wi = f >> 1;
         const uint32_t cur = wi == 0 ? e.x : (wi == 1 ? e.y : (wi == 2 ? e.z : e.w));
         const uint32_t nw = (f & 1) ? ((cur & 0x0000FFFFu) | (t << 16)) : ((cur & 0xFFFF0000u) | t);
-        if (atomicCAS(&v.tab[4u * b + (uint32_t)wi], cur, nw) == cur) return kQRoom;
+        if (atomicCAS(&v.tab[4u * b + (uint32_t)wi], cur, nw) == cur) { idx = (int)(8u * b) + f; return kQRoom; }
     }
+}
+__device__ __forceinline__ int q16_insert(const Visited& v, uint32_t pid) {
+    int idx;
+    return q16_insert(v, pid, idx);
+}
+// index of pid in the on-chip set, whichever form it has (-1: not there)
+__device__ __forceinline__ int vis_index(const Visited& v, uint32_t pid) {
+    return v.q16 ? q16_index(v, pid) : (v.tab ? tab_index(v, pid) : -1);
 }
 // Visited::clear (core/types.rs:48-58): empty the on-chip set / zero the dirty blocks.  Wave-uniform control flow.
 __device__ __forceinline__ void visited_clear(Visited& v) {
@@ -762,7 +788,7 @@ __device__ __forceinline__ void visited_mark(const Visited& v, uint32_t pid) {
 __device__ __forceinline__ bool visited_insert(const Visited& v, uint32_t pid, int& tab_idx) {
     tab_idx = -1;
     if (v.q16) {
-        const int r = q16_insert(v, pid);
+        const int r = q16_insert(v, pid, tab_idx);
         if (r != kQFull) return r == kQRoom;
     } else if (v.tab) {
         if (!v.spill) { tab_idx = tab_insert(v, pid); return tab_idx >= 0; }
@@ -830,6 +856,52 @@ __device__ __forceinline__ void dlog_publish(const DistLog& L, const Visited& v,
 __device__ __forceinline__ uint32_t dlog_find(const uint32_t* PD, uint32_t bmask, uint32_t bshift, uint32_t pid) {
     const int i = tabset_index<8>(PD, bmask, bshift, pid);
     return i >= 0 ? PD[i + 4] : kDlogMiss;
+}
+// The same for the quotient form of the set: one 64-B record per bucket = its eight 16-bit entries (16 B), their eight
+// distances (32 B), 16 B unused — a lookup touches one record per home bucket, the distance sits in the line the
+// entries came from.  The set holds twice as many entries as it has dwords, so the distances are sorted through its LDS
+// in two halves (each half re-reads the log, which is still in L2).
+__device__ __forceinline__ void dlog_publish_q16(const DistLog& L, const Visited& v, uint32_t* out_pd) {
+    const int lane = lane_id();
+    wave_sync();
+    uint4* t = reinterpret_cast<uint4*>(v.tab);
+    uint4* o = reinterpret_cast<uint4*>(out_pd);
+    const uint32_t nbuck = v.tmask + 1u, half = 4u * nbuck;          // entries per half = dwords of the set
+    for (uint32_t i = lane; i < nbuck; i += 64) o[4u * i] = t[i];
+    visited_drain();                                       // the log's own stores have landed before it is read back
+    wave_sync();
+    constexpr int kDeep = 8;
+    for (uint32_t h = 0; h < 2u; h++) {
+        for (uint32_t base = 0; base < L.n; base += 64u * kDeep) {
+            uint64_t e[kDeep];
+#pragma unroll
+            for (int u = 0; u < kDeep; u++) {
+                const uint32_t i = base + 64u * (uint32_t)u + (uint32_t)lane;
+                e[u] = L.log[i < L.n ? i : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < kDeep; u++) {
+                const uint32_t idx = (uint32_t)e[u];
+                if (base + 64u * (uint32_t)u + (uint32_t)lane < L.n && idx / half == h) v.tab[idx - h * half] = (uint32_t)(e[u] >> 32);
+            }
+        }
+        wave_sync();
+        // dword j of the set's LDS now is the distance of entry h * half + j: four of them = half a bucket
+        for (uint32_t i = lane; i < nbuck; i += 64) {
+            const uint32_t ent = h * half + 4u * i;                    // first entry of this group of four
+            o[4u * (ent >> 3) + 1u + ((ent >> 2) & 1u)] = t[i];
+        }
+        wave_sync();
+    }
+}
+__device__ __forceinline__ uint32_t dlog_find_q16(const uint32_t* PD, uint32_t ubits, uint32_t rbits, uint32_t pid) {
+    const Q16Keys k = q16_keys(ubits, rbits, pid);
+    const uint32_t* r1 = PD + 16u * k.b1;
+    const int s1 = q16_slot(*reinterpret_cast<const uint4*>(r1), k.t1);
+    if (s1 >= 0) return r1[4 + s1];
+    const uint32_t* r2 = PD + 16u * k.b2;
+    const int s2 = q16_slot(*reinterpret_cast<const uint4*>(r2), k.t2);
+    return s2 >= 0 ? r2[4 + s2] : kDlogMiss;
 }
 
 struct Counters {
@@ -900,7 +972,7 @@ __device__ __forceinline__ void push_entry(const IndexView& ix, const float* q, 
     dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, 1);
     wave_sync();
     if (lane == 0) st.W[0] = ((uint64_t)act_dist[0] << 32);  // pid 0
-    if (dlog.log) dlog_append(dlog, lane == 0 && vis.tab ? tab_index(vis, 0u) : -1, act_dist[0]);
+    if (dlog.log) dlog_append(dlog, lane == 0 ? vis_index(vis, 0u) : -1, act_dist[0]);
     wave_sync();
     st.plen = 1;
     st.cursor = 0;
@@ -1054,7 +1126,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             // set while their rows are in flight; the test-and-set of the others is in flight during that pass, and
             // those that turn out new get a second pass.  Keys are pushed in slot order afterwards, whichever pass
             // computed them.
-            int stt = kQFound;
+            int stt = kQFound, tab_idx = -1;
             uint32_t vold = 0;
             const uint32_t vbit = 1u << (nb_pid & 31u);
             if (is_nb) {
@@ -1074,7 +1146,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 if (sure) act_pid[my] = nb_pid;                                         // keeps slot order
                 wave_sync();
                 auto mid = [&]() {
-                    if (sure && q16_insert(vis, nb_pid) == kQFull) {                    // filled up by this very expansion
+                    if (sure && q16_insert(vis, nb_pid, tab_idx) == kQFull) {           // filled up by this very expansion
                         atomicOr(&vis.bits[nb_pid >> 5], vbit);
                         visited_note(vis, nb_pid);
                     }
@@ -1110,6 +1182,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 ctr.n_dist += (uint32_t)na;
                 uint64_t key = kMaxKey;
                 if (fresh) key = ((uint64_t)my_d << 32) | nb_pid;
+                if (dlog.log) dlog_append(dlog, fresh ? tab_idx : -1, my_d);            // (ids that went to the bitmap have no index)
                 w_push_keys(st, key, fresh);
             }
         } else if constexpr (!OVL) {
@@ -1200,7 +1273,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 ctr.n_dist += (uint32_t)na;
                 uint64_t key = kMaxKey;
                 if (fresh) key = ((uint64_t)my_d << 32) | nb_pid;
-                if (dlog.log) dlog_append(dlog, fresh && vis.tab ? tab_index(vis, nb_pid) : -1, my_d);
+                if (dlog.log) dlog_append(dlog, fresh ? vis_index(vis, nb_pid) : -1, my_d);
                 w_push_keys(st, key, fresh);
             }
         }

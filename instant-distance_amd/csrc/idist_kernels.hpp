@@ -390,7 +390,10 @@ struct BuildArgs {
     // distance log of every new point's descent (DistLog): append log, then the published set ids / distances
     uint64_t* dlog_log;         // [max_batch][1 << tab_log2]
     uint32_t* dlog_pd;          // [max_batch][2 << tab_log2] published sets: per bucket four ids + their four distances
-    uint32_t tab_log2;          // log2(ids) of the descent's on-chip visited set
+    uint32_t tab_log2;          // LDS of the descent's on-chip visited set: 4 << tab_log2 bytes
+    uint32_t tab16;             // 1: that set stores 16-bit quotients (2 << tab_log2 ids), else full ids (1 << tab_log2)
+    uint32_t ubits;             // quotient form: bits of the id universe
+    uint32_t dl_shift;          // log2(entries) of one insertion's distance log = tab_log2 + tab16; its published set takes 2 << dl_shift dwords
     uint32_t use_dlog;          // 0: nothing is logged, step B computes every distance it needs (IDIST_BUILD_NO_DLOG, test / A-B knob)
     uint64_t* wbuf;             // [max_batch][efc] Search.nearest of every new point (step A -> step A2)
     uint32_t* wcount;           // [max_batch]
@@ -465,7 +468,7 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
                 for (int i0 = 0; i0 < st.plen; i0 += 64) {
                     const bool on = i0 + lane < st.plen;
                     const uint64_t k = on ? st.W[i0 + lane] & kKeyMask : 0ull;
-                    dlog_append(dl, on ? tab_index(vis, (uint32_t)k) : -1, (uint32_t)(k >> 32));
+                    dlog_append(dl, on ? vis_index(vis, (uint32_t)k) : -1, (uint32_t)(k >> 32));
                 }
         } else {                                                  // :458-461
             search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dl);
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
     const uint32_t slot = blockIdx.x;
     Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words, nullptr, 0};
     visited_attach_tab(vis, sm.bloom, a.tab_log2);                    // the descent always keeps its visited set on chip
+    if constexpr (walk_vis16(LAT)) visited_attach_q16(vis, a.tab_log2, a.ubits);
     uint32_t status = 0;
     Counters tot{0, 0, 0};
     for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
@@ -495,14 +499,18 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
         const uint32_t nw_pid = a.start + item;
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
         // only the heuristic's re-selections look distances up
-        DistLog dl{a.has_heuristic && a.use_dlog ? a.dlog_log + ((size_t)item << a.tab_log2) : nullptr, 0u};
+        DistLog dl{a.has_heuristic && a.use_dlog ? a.dlog_log + ((size_t)item << a.dl_shift) : nullptr, 0u};
         insert_descent<NB, RS, TAIL, LAT>(ix, a, sm, st, vis, nw_pid, tot, dl);
         const int nw = st.plen < st.ef ? st.plen : st.ef;             // Search.nearest
         if (a.has_heuristic) {
             // select_heuristic (:470-472) runs in step A2 with the selected rows on chip; hand Search.nearest over
             for (int i = lane; i < nw; i += 64) a.wbuf[(size_t)item * a.efc + i] = st.W[i] & kKeyMask;
             if (lane == 0) a.wcount[item] = (uint32_t)nw;
-            if (dl.log) dlog_publish(dl, vis, a.dlog_pd + ((size_t)item << (a.tab_log2 + 1u)));
+            if (dl.log) {
+                uint32_t* pd = a.dlog_pd + ((size_t)item << (a.dl_shift + 1u));
+                if constexpr (walk_vis16(LAT)) dlog_publish_q16(dl, vis, pd);
+                else dlog_publish(dl, vis, pd);
+            }
         } else {                                                      // select_simple, :466-469, :758-760
             const int nsel = nw < kM2 ? nw : kM2;
             if (lane < nsel) sel[lane] = st.W[lane] & kKeyMask;
@@ -973,10 +981,10 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             const uint32_t new_pid = (uint32_t)knew, cd_new = (uint32_t)(knew >> 32);
             const bool selL = lane < ns0, discL = lane >= ns0 && lane < ncur;
             const uint64_t below = (1ull << lane) - 1ull;
-            const uint32_t* TPD = a.dlog_pd + ((size_t)(new_pid - a.start) << (a.tab_log2 + 1u));
+            const uint32_t* TPD = a.dlog_pd + ((size_t)(new_pid - a.start) << (a.dl_shift + 1u));
             const uint32_t bmask = (1u << (a.tab_log2 - 2u)) - 1u, bshift = 32u - (a.tab_log2 - 2u);
             uint32_t dn = kDlogMiss;                         // d(new, selected entry of this lane)
-            if (selL && a.use_dlog) dn = dlog_find(TPD, bmask, bshift, cur);
+            if (selL && a.use_dlog) dn = a.tab16 ? dlog_find_q16(TPD, a.ubits, a.ubits - (a.tab_log2 - 2u), cur) : dlog_find(TPD, bmask, bshift, cur);
             const bool miss = selL && dn == kDlogMiss;
             const uint64_t mm = __ballot(miss);
             if (mm) {
@@ -1071,10 +1079,10 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             const int nx = ns0 + k_new;
             for (int ai = 0; ai < k_new; ai++) {
                 const uint32_t a_pid = (uint32_t)news[ai];
-                const uint32_t* TPD = a.dlog_pd + ((size_t)(a_pid - a.start) << (a.tab_log2 + 1u));
+                const uint32_t* TPD = a.dlog_pd + ((size_t)(a_pid - a.start) << (a.dl_shift + 1u));
                 const uint32_t bmask = (1u << (a.tab_log2 - 2u)) - 1u, bshift = 32u - (a.tab_log2 - 2u);
                 uint32_t dv = kDlogMiss;
-                if (lane < ns0 && a.use_dlog) dv = dlog_find(TPD, bmask, bshift, X[lane]);
+                if (lane < ns0 && a.use_dlog) dv = a.tab16 ? dlog_find_q16(TPD, a.ubits, a.ubits - (a.tab_log2 - 2u), X[lane]) : dlog_find(TPD, bmask, bshift, X[lane]);
                 if (lane < ns0) Dn[ai * kFastX + lane] = dv;
                 int nmiss = 0;
                 // columns [0, ns0) that missed + the other new points: gather those rows

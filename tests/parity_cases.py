@@ -37,6 +37,8 @@ BUILD_VARIANTS = (("on-chip", {}),
                   ("reference-order kernels: LDS-tile selection, every update from scratch", {"IDIST_BUILD_A2": "tile", "IDIST_BUILD_NO_FAST": "1"}),
                   ("step A2 with the LDS-tile kernel instead of the Gram matrix on MFMA", {"IDIST_BUILD_A2": "tile"}),
                   ("on-chip classic", {"IDIST_WALK": "classic"}),
+                  ("on-chip, full ids (frozen at 7/8, distance log in the id form)", {"IDIST_TAB_FORMAT": "ids"}),
+                  ("on-chip, full ids, small set then bitmap", {"IDIST_TAB_FORMAT": "ids", "IDIST_TAB_LOG2": "7"}),
                   ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7"}),
                   ("on-chip, set of 32 ids: bitmap from the start", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}))
 
