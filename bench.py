@@ -30,6 +30,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one hardware queue per host thread of the scalar-call measurement (libidist sets the same default when it is the first HIP
+# user of a process; here torch starts the runtime, so it has to be in the environment before `import torch`)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md chip table: 8.0 TB/s spec (6.29 TB/s measured copy)
 

@@ -29,7 +29,9 @@
  *   IDIST_VISITED=bitmap|onchip  force the bitmap + Bloom-filter walk / the on-chip visited set, whatever the policy says
  *   IDIST_TAB_LOG2=<5..13>  LDS of the on-chip visited set, 4 << n bytes (small sets exercise the overflow to the
  *                           bitmap; the build clamps it to >= 8); also forces the on-chip walk
- *   IDIST_TAB_FORMAT=ids    the on-chip set of a search keeps full ids (frozen at 7/8) instead of 16-bit quotients
+ *   IDIST_TAB_FORMAT=ids|q16  the on-chip visited set always keeps full ids (4 per bucket, frozen at 7/8) / 16-bit quotients
+ *                           (8 per bucket, single ids overflow) wherever they apply, whatever the policy says
+ *   IDIST_BUILD_A_REGS=512  descents with one 512-register wave per SIMD instead of 256-register waves
  *   IDIST_QUAD_NQ=<n>       batches of <= n queries run four waves per query (default two queries per CU; 0 = never)
  *   IDIST_LATENCY_NQ=<n>    bitmap walk only: batches of <= n queries run its latency variant (default 1024)
  *   IDIST_BLOOM=0           bitmap walk without the LDS Bloom filter
@@ -38,7 +40,7 @@
  *   IDIST_BUILD_PIPELINE=0  concurrent builds without the two-stream pipeline (a new point then sees all points up
  *                           to the previous step instead of the one before; graphs differ, quality does not)
  *   IDIST_BUILD_CHECK=1     self-check at the end of a pipelined build: both copies of the zero layer must agree
- *   IDIST_BUILD_A_WAVES=<1..4>  descent waves per CU in the pipelined schedule (default 3)
+ *   IDIST_BUILD_A_WAVES=<1..8>  descent waves per CU in the pipelined schedule (default 4; 3 with the id set)
  *   IDIST_BUILD_A2=tile     new points' select_heuristic with the LDS-tile kernel instead of the Gram matrix on MFMA
  *   IDIST_BUILD_NO_FAST=1   every neighbour update through the from-scratch kernel (no memoised re-selection)
  *   IDIST_BUILD_NO_DLOG=1   the memoised re-selection recomputes every distance instead of looking it up

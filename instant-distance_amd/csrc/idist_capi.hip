@@ -26,6 +26,15 @@
 
 using namespace idist;
 
+#ifndef IDIST_EMU
+// The reference's concurrency model is one `Search` per host thread on a shared index (core/lib.rs:352-356): every context
+// owns a stream, and the one-workgroup kernels of scalar calls only overlap if those streams sit on different hardware
+// queues.  The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES queues (default 4) and reads the
+// variable when it starts: 16 threads reach 6.3k calls/s on 4 queues, 14.3k on 16 (profiles/probe_r03b_scalar_calls_*).
+// Set it — unless the host already did — when the library is loaded, i.e. before its first HIP call.
+__attribute__((constructor)) static void idist_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -171,8 +180,9 @@ struct Knobs {
     bool vis_bitmap = false;      // IDIST_VISITED=bitmap: search with bitmap + Bloom filter (16 waves per CU) instead of the on-chip set
     bool vis_onchip = false;      // IDIST_VISITED=onchip: the on-chip set whatever the policy says (test / A-B knob)
     bool events = true;           // IDIST_KERNEL_EVENTS=0: no HIP events around the search kernels (idist_search_ctx_kernel_times then has nothing)
-    bool tab_ids = false;         // IDIST_TAB_FORMAT=ids: the on-chip set of a search keeps full ids (4 per bucket, frozen at 7/8) instead of
+    bool tab_ids = false;         // IDIST_TAB_FORMAT=ids: the on-chip set always keeps full ids (4 per bucket, frozen at 7/8), never
                                   // 16-bit quotients (8 per bucket, single ids overflow) (test / A-B knob)
+    bool tab_q16 = false;         // IDIST_TAB_FORMAT=q16: quotients wherever they apply, also where the policy would keep ids
     bool no_zero_copy = false;    // IDIST_NO_ZERO_COPY=1: narrow host-pointer batches take the general (staged) path too (test / A-B knob)
     int tune = -1;                // IDIST_TUNE=<i> (tuning builds only, -DIDIST_TUNE): i-th experimental walk variant
     uint32_t quad_nq = 0xFFFFFFFFu;   // IDIST_QUAD_NQ: batches up to this many queries run four waves per query (default: two
@@ -186,7 +196,7 @@ struct Knobs {
         if (const char* e = getenv("IDIST_BLOOM")) k.bloom = e[0] != '0';
         if (const char* e = getenv("IDIST_VISITED")) { k.vis_bitmap = e[0] == 'b'; k.vis_onchip = e[0] == 'o'; }
         if (const char* e = getenv("IDIST_NO_ZERO_COPY")) k.no_zero_copy = e[0] != '0';
-        if (const char* e = getenv("IDIST_TAB_FORMAT")) k.tab_ids = e[0] == 'i';
+        if (const char* e = getenv("IDIST_TAB_FORMAT")) { k.tab_ids = e[0] == 'i'; k.tab_q16 = e[0] == 'q'; }
         if (const char* e = getenv("IDIST_KERNEL_EVENTS")) k.events = e[0] != '0';
         if (const char* e = getenv("IDIST_TAB_LOG2")) k.tab_log2 = std::min(13u, std::max(5u, (uint32_t)atoi(e)));
         return k;
@@ -409,7 +419,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     uint32_t* d_vis = nullptr;
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
-    uint32_t* d_small = nullptr;           // [0] n_touched, [1..5] queue (A, B, n_slow, B2, A2), [6] status
+    uint32_t* d_small = nullptr;           // [0] n_touched, [1..6] queue (A, B, n_slow, B2, A2, A3), [8] status
     uint64_t *d_wbuf = nullptr, *d_dlog_log = nullptr;
     uint32_t* d_dlog_pd = nullptr;
     uint32_t* d_wcount = nullptr;
@@ -428,8 +438,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     // the descents (8-12 waves per CU saturate their HBM stream) leave wave slots and LDS to the other stream
     uint32_t a_waves = tab16 ? 4u : 3u;
     if (const char* e = getenv("IDIST_BUILD_A_WAVES")) a_waves = (uint32_t)std::min(8, std::max(1, atoi(e)));
-    bool a_regs256 = false;               // IDIST_BUILD_A_REGS=256: the two-waves-per-SIMD instantiation of the descent (quotient set only)
-    if (const char* e = getenv("IDIST_BUILD_A_REGS")) a_regs256 = atoi(e) == 256;
+    // the descent's register budget (quotient set only): 256 registers per wave (two waves fit a SIMD: the update stream's
+    // waves find room on every SIMD) or 512 (IDIST_BUILD_A_REGS=512, more rounds in flight per wave).  C3: 1.26 vs 1.29-1.32 s
+    bool a_regs256 = tab16;
+    if (const char* e = getenv("IDIST_BUILD_A_REGS")) a_regs256 = tab16 && atoi(e) == 256;
     // what one CU's LDS holds of them (the sequential schedule runs nothing beside the descents)
     const uint32_t a_waves_max = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)((160u * 1024u) / smem)));
     a_waves = std::min(a_waves, a_waves_max);
@@ -515,7 +527,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     a.n_touched = d_small;
     a.queue = d_small + 1;
     a.n_slow = d_small + 3;      // == &queue[2]
-    a.status = d_small + 6;
+    a.status = d_small + 8;
     a.dlog_log = d_dlog_log;
     a.dlog_pd = d_dlog_pd;
     a.tab_log2 = tab_log2;
@@ -542,7 +554,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     hipStream_t stream = pipe ? s1 : nullptr;
     uint32_t* zbuf[2] = {ix->d_zero, pipe ? d_zero2 : ix->d_zero};     // copy k&1 holds the state after step k
     uint32_t* const smallS = d_small + (pipe ? 16 : 0);                // step A2/B/B2 counters (own stream)
-    uint32_t* const d_status = d_small + (pipe ? 32 : 6);
+    uint32_t* const d_status = d_small + (pipe ? 32 : 8);
     a.n_touched = smallS;
     a.status = d_status;
     uint64_t n_batches = 0;
@@ -582,7 +594,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
                 aA.wcount = d_wcount + (size_t)par * cap;
                 BCHK(hipMemsetAsync(d_small, 0, 8, sA));                  // step A queue head
             } else {
-                BCHK(hipMemsetAsync(d_small, 0, 24, sA));                 // n_touched, queue heads, n_slow
+                BCHK(hipMemsetAsync(d_small, 0, 32, sA));                 // n_touched, queue heads, n_slow
             }
             const uint32_t gridA = std::min(B, std::min<uint32_t>(slots, (uint32_t)ix->n_cu * (pipe ? a_waves : std::min(a_waves_max, a_regs256 ? 8u : 4u))));
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
@@ -601,7 +613,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         auto kA16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true, false, true)>; \
         auto kAo16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
         /* two descent waves per SIMD: 256 registers each, fewer rounds in flight per wave, more waves */ \
-        auto kAo16w2 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 2 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
+        auto kAo16w2 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
         auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
@@ -618,7 +630,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
             BCHK(hipEventRecord(evA[par], s1));                                                    \
             BCHK(hipStreamWaitEvent(s2, evA[par], 0));                                             \
             IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s2, zbuf[par ^ 1], zbuf[par], a.touched, smallS, prev_start, prev_count); \
-            BCHK(hipMemsetAsync(smallS, 0, 24, s2));                                               \
+            BCHK(hipMemsetAsync(smallS, 0, 32, s2));                                               \
         }                                                                                          \
         if (ext) {                                                                                 \
         } else if (cfg.has_heuristic) {                                                            \
@@ -796,7 +808,11 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     a.tab_log2 = tab_log2;
     // the set stores 16-bit quotients (twice the ids in the same LDS) whenever n allows it: up to 33M points with 32 KB
     a.ubits = on_chip ? q16_universe_bits(ix->n, tab_log2) : 0u;
-    const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits);
+    // ... and the walk can outgrow the id form: a search visits ~53 * ef_search + 600 nodes (C3 / C4 / C5 data alike); while that
+    // stays below the 7/8 * 2^tab_log2 ids the plain set takes, the plain set never spills and its cheaper probe wins by
+    // 1-2 % (ef_search = 100: 10.25 vs 10.42 ms per 10k queries at C3, profiles/probe_r03a_ef_paths_*)
+    const bool ids_suffice = 53u * ef + 600u <= (7u << tab_log2) / 8u;
+    const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits) && (ctx->knobs.tab_q16 || ctx->knobs.tab_log2 || !ids_suffice);
     uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (on_chip ? 4u : 16u));   // quad: two workgroups per CU where registers allow
 #ifdef IDIST_TUNE
     if (const char* e = getenv("IDIST_WAVES_PER_CU")) resident = (uint32_t)ix->n_cu * (uint32_t)std::max(1, atoi(e));   // tuning builds only

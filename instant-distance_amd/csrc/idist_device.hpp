@@ -896,12 +896,16 @@ __device__ __forceinline__ void dlog_publish_q16(const DistLog& L, const Visited
 }
 __device__ __forceinline__ uint32_t dlog_find_q16(const uint32_t* PD, uint32_t ubits, uint32_t rbits, uint32_t pid) {
     const Q16Keys k = q16_keys(ubits, rbits, pid);
-    const uint32_t* r1 = PD + 16u * k.b1;
-    const int s1 = q16_slot(*reinterpret_cast<const uint4*>(r1), k.t1);
-    if (s1 >= 0) return r1[4 + s1];
-    const uint32_t* r2 = PD + 16u * k.b2;
-    const int s2 = q16_slot(*reinterpret_cast<const uint4*>(r2), k.t2);
-    return s2 >= 0 ? r2[4 + s2] : kDlogMiss;
+    // entries and distances of a record come in ONE round trip (three 16-B loads of one 64-B line), not entries first
+    auto probe = [](const uint32_t* r, uint32_t t) -> uint32_t {
+        const uint4 e = *reinterpret_cast<const uint4*>(r);
+        const uint4 d0 = *reinterpret_cast<const uint4*>(r + 4), d1 = *reinterpret_cast<const uint4*>(r + 8);
+        const int s = q16_slot(e, t);
+        return s < 0 ? kDlogMiss : (s == 0 ? d0.x : (s == 1 ? d0.y : (s == 2 ? d0.z : (s == 3 ? d0.w : (s == 4 ? d1.x : (s == 5 ? d1.y : (s == 6 ? d1.z : d1.w)))))));
+    };
+    const uint32_t v1 = probe(PD + 16u * k.b1, k.t1);
+    if (v1 != kDlogMiss) return v1;
+    return probe(PD + 16u * k.b2, k.t2);
 }
 
 struct Counters {

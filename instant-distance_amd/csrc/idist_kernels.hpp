@@ -894,6 +894,13 @@ __global__ __launch_bounds__(64) void build_update_simple_kernel(IndexView ix, B
 // full re-selection (step B2, build_update_kernel).  Results are identical by
 // construction; tests/test_parity.py checks byte-identity with the oracle.
 // ---------------------------------------------------------------------------
+// step B: d(new point, pid) from the set the new point's descent published, kDlogMiss if it is not there
+__device__ __forceinline__ uint32_t build_dlog_find(const BuildArgs& a, uint32_t new_pid, uint32_t pid) {
+    const uint32_t* TPD = a.dlog_pd + ((size_t)(new_pid - a.start) << (a.dl_shift + 1u));
+    if (a.tab16) return dlog_find_q16(TPD, a.ubits, a.ubits - (a.tab_log2 - 2u), pid);
+    return dlog_find(TPD, (1u << (a.tab_log2 - 2u)) - 1u, 32u - (a.tab_log2 - 2u), pid);
+}
+
 constexpr int kUpdW = 136;   // <= 64 current + 64 new + slack
 constexpr int kMaxNewFast = 8;
 constexpr int kFastX = 80;   // columns of the new-vs-{old selected, new} distance table
@@ -950,10 +957,20 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
         // the new points that chose `pid` (inbox), nearest first
         WState ns{news, 0, kM2, 0, 0u};
         uint32_t e = a.head[pid];
+        // Nearly every update has ONE new point, and which one is known as soon as the inbox head is: look its distances
+        // to the row's selected members up NOW, in flight together with the inbox walk (edge_dist / next), instead of
+        // after it.  (Several new points: the value is simply not used.)
+        uint32_t ed0 = 0, en0 = kInvalid;
+        if (e != kInvalid) { ed0 = a.edge_dist[e]; en0 = a.next[e]; }   // (requested first: the probe below waits for its own loads)
+        uint32_t dn_spec = kDlogMiss;
+        if (e != kInvalid && a.use_dlog && lane < ns0 && cur != kInvalid)
+            dn_spec = build_dlog_find(a, a.start + e / kM2, cur);
         uint32_t guard = 0;
+        bool first_edge = true;
         while (e != kInvalid) {
-            const uint32_t ed = a.edge_dist[e];
-            const uint32_t en = a.next[e];
+            const uint32_t ed = first_edge ? ed0 : a.edge_dist[e];
+            const uint32_t en = first_edge ? en0 : a.next[e];
+            first_edge = false;
             const uint64_t k = ((uint64_t)ed << 32) | (a.start + e / kM2);
             const int idx = w_rank(ns, k);
             if (idx < ns.ef) w_insert(ns, idx, k);
@@ -981,10 +998,7 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             const uint32_t new_pid = (uint32_t)knew, cd_new = (uint32_t)(knew >> 32);
             const bool selL = lane < ns0, discL = lane >= ns0 && lane < ncur;
             const uint64_t below = (1ull << lane) - 1ull;
-            const uint32_t* TPD = a.dlog_pd + ((size_t)(new_pid - a.start) << (a.dl_shift + 1u));
-            const uint32_t bmask = (1u << (a.tab_log2 - 2u)) - 1u, bshift = 32u - (a.tab_log2 - 2u);
-            uint32_t dn = kDlogMiss;                         // d(new, selected entry of this lane)
-            if (selL && a.use_dlog) dn = a.tab16 ? dlog_find_q16(TPD, a.ubits, a.ubits - (a.tab_log2 - 2u), cur) : dlog_find(TPD, bmask, bshift, cur);
+            uint32_t dn = selL ? dn_spec : kDlogMiss;        // d(new, selected entry of this lane), requested before the inbox walk
             const bool miss = selL && dn == kDlogMiss;
             const uint64_t mm = __ballot(miss);
             if (mm) {
@@ -1079,10 +1093,8 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             const int nx = ns0 + k_new;
             for (int ai = 0; ai < k_new; ai++) {
                 const uint32_t a_pid = (uint32_t)news[ai];
-                const uint32_t* TPD = a.dlog_pd + ((size_t)(a_pid - a.start) << (a.dl_shift + 1u));
-                const uint32_t bmask = (1u << (a.tab_log2 - 2u)) - 1u, bshift = 32u - (a.tab_log2 - 2u);
                 uint32_t dv = kDlogMiss;
-                if (lane < ns0 && a.use_dlog) dv = a.tab16 ? dlog_find_q16(TPD, a.ubits, a.ubits - (a.tab_log2 - 2u), X[lane]) : dlog_find(TPD, bmask, bshift, X[lane]);
+                if (lane < ns0 && a.use_dlog) dv = build_dlog_find(a, a_pid, X[lane]);
                 if (lane < ns0) Dn[ai * kFastX + lane] = dv;
                 int nmiss = 0;
                 // columns [0, ns0) that missed + the other new points: gather those rows

@@ -24,7 +24,9 @@ namespace idist {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 
-constexpr int kTM = 128, kTN = 128, kKC = 16, kLDP = kKC + 1;   // tile, K chunk, padded LDS pitch
+// tile, K chunk, LDS pitch: 36 floats = 16-B aligned rows, and 36 = 4 * 9 with 9 odd, so 16 lanes reading float4s of rows
+// that differ mod 16 hit 64 distinct banks (ds_read_b128 / ds_write_b128 conflict-free)
+constexpr int kTM = 128, kTN = 128, kKC = 32, kLDP = 36;
 
 // |row|^2 in storage order (one wave per row)
 __global__ __launch_bounds__(64) void row_norms_kernel(const float* __restrict__ rows, uint32_t n, uint32_t stride,
@@ -78,33 +80,53 @@ __global__ __launch_bounds__(256) void mfma_dist_kernel(MfmaArgs a) {
         for (int j = 0; j < 2; j++)
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    const int srow = tid >> 2, scol = (tid & 3) << 2;                 // staging: 4 threads x float4 per 64-B row chunk
+    // K loop: one 32-float chunk of the 128 query rows and the 128 point rows per iteration.  The next chunk is requested
+    // (global -> registers) before the current one's 64 MFMAs per wave, operands move as float4s, and inside a chunk
+    // instruction #j contracts elements j (lanes 0-31) and 16 + j (lanes 32-63), so a lane's sixteen operands of a row
+    // are contiguous.  (Stored rows are a multiple of 16 floats: a chunk is full or half full, the rest is zero.)
+    auto fetch = [&](uint32_t kc, float4 (&va)[4], float4 (&vb)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = tid + 256 * u;                                // 1024 float4 = 128 rows x 8
+            const int row = idx >> 3, part = (idx & 7) << 2;
+            va[u].x = va[u].y = va[u].z = va[u].w = 0.0f;
+            vb[u] = va[u];
+            if (kc + (uint32_t)part < a.stride) {
+                // rows past the end re-read the last valid row (masked in the epilogue); Q is padded to a tile multiple
+                uint32_t gp = p0 + row;
+                if (gp >= a.n) gp = a.n - 1;
+                va[u] = *reinterpret_cast<const float4*>(a.Q + (size_t)(q0 + row) * a.stride + kc + part);
+                vb[u] = *reinterpret_cast<const float4*>(a.P + (size_t)gp * a.stride + kc + part);
+            }
+        }
+    };
+    float4 pa[4], pb[4];
+    fetch(0u, pa, pb);
     for (uint32_t kc = 0; kc < a.stride; kc += kKC) {
-        for (int pass = 0; pass < 2; pass++) {
-            const int row = pass * 64 + srow;
-            // rows past the end re-read the last valid row (masked in the epilogue)
-            const uint32_t gq = q0 + row;                             // Q is padded to a tile multiple
-            uint32_t gp = p0 + row;
-            if (gp >= a.n) gp = a.n - 1;
-            const float4 va = *reinterpret_cast<const float4*>(a.Q + (size_t)gq * a.stride + kc + scol);
-            const float4 vb = *reinterpret_cast<const float4*>(a.P + (size_t)gp * a.stride + kc + scol);
-            float* da = As + row * kLDP + scol;
-            float* db = Bs + row * kLDP + scol;
-            da[0] = va.x; da[1] = va.y; da[2] = va.z; da[3] = va.w;
-            db[0] = vb.x; db[1] = vb.y; db[2] = vb.z; db[3] = vb.w;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = tid + 256 * u;
+            const int off = (idx >> 3) * kLDP + ((idx & 7) << 2);
+            *reinterpret_cast<float4*>(As + off) = pa[u];
+            *reinterpret_cast<float4*>(Bs + off) = pb[u];
         }
         __syncthreads();
+        if (kc + kKC < a.stride) fetch(kc + kKC, pa, pb);
+        const float* ap = As + (wr * 64 + (lane & 31)) * kLDP + 16 * (lane >> 5);
+        const float* bp = Bs + (wc * 64 + (lane & 31)) * kLDP + 16 * (lane >> 5);
 #pragma unroll
-        for (int kk = 0; kk < kKC / 2; kk++) {
-            const int kcol = kk * 2 + (lane >> 5);
-            const float a0 = As[(wr * 64 + (lane & 31)) * kLDP + kcol];
-            const float a1 = As[(wr * 64 + 32 + (lane & 31)) * kLDP + kcol];
-            const float b0 = Bs[(wc * 64 + (lane & 31)) * kLDP + kcol];
-            const float b1 = Bs[(wc * 64 + 32 + (lane & 31)) * kLDP + kcol];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int q = 0; q < 4; q++) {
+            const float4 a0 = *reinterpret_cast<const float4*>(ap + 4 * q);
+            const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * kLDP + 4 * q);
+            const float4 b0 = *reinterpret_cast<const float4*>(bp + 4 * q);
+            const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * kLDP + 4 * q);
+#define IDIST_MFMA4(X_)                                                                      \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.X_, b0.X_, acc[0][0], 0, 0, 0);  \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.X_, b1.X_, acc[0][1], 0, 0, 0);  \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.X_, b0.X_, acc[1][0], 0, 0, 0);  \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.X_, b1.X_, acc[1][1], 0, 0, 0);
+            IDIST_MFMA4(x) IDIST_MFMA4(y) IDIST_MFMA4(z) IDIST_MFMA4(w)
+#undef IDIST_MFMA4
         }
         __syncthreads();
     }
@@ -246,7 +268,9 @@ __global__ __launch_bounds__(64) void rerank_kernel(IndexView ix, const float* _
 // One 256-thread workgroup per new point: the four waves share the staged K-chunks (128 rows x 32 floats) and own
 // the ten lower-triangle 32 x 32 tiles 3/3/2/2; wave 0 runs the selection.  28 KB of LDS, < 128 VGPRs.
 // ---------------------------------------------------------------------------
-constexpr int kGramRows = 128, kGramChunk = 32, kGramPitch = kGramChunk + 1;
+// pitch 36 floats: 16-B aligned rows, and 36 = 4 * 9 with 9 odd => any 16 lanes reading float4s of rows that differ mod 16 hit
+// 64 distinct banks (ds_read_b128 / ds_write_b128 without conflicts)
+constexpr int kGramRows = 128, kGramChunk = 32, kGramPitch = 36;
 constexpr float kGramEps = 4.0f * 5.9604645e-8f;    // 4 * 2^-24 per stored element, times the row length at run time
 
 __host__ __device__ inline size_t smem_bytes_select_mfma(uint32_t stride) {
@@ -309,28 +333,48 @@ __global__ __launch_bounds__(256) IDIST_A2M_ATTR void build_select_mfma_kernel(I
         f32x16 acc[3];
         for (int t = 0; t < 3; t++)
             for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
-        // ---- Gram matrix: G = C * C^T over the stored row length, one 32-float chunk at a time
-        for (uint32_t kc = 0; kc < ix.stride; kc += kGramChunk) {
+        // ---- Gram matrix: G = C * C^T over the stored row length, one 32-float chunk at a time.  The next chunk's rows are
+        //      requested (global -> registers) before the current chunk's MFMAs, so HBM latency hides behind the matrix
+        //      pipe; operands move as float4s (ds_write_b128 / ds_read_b128).  K order inside a chunk: the instruction
+        //      v_mfma_f32_32x32x2_f32 #j contracts elements j (lanes 0-31) and 16 + j (lanes 32-63) — a lane's sixteen
+        //      operands are contiguous in its row.  (Any fixed order of the sum is a valid Gram entry for the filter.)
+        auto fetch = [&](uint32_t kc, float4 (&v)[4]) {
+#pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int idx = tid + 256 * u;                           // 1024 float4 = 128 rows x 8
                 const int row = idx >> 3, part = (idx & 7) << 2;
-                float4 v;
-                v.x = v.y = v.z = v.w = 0.0f;
+                v[u].x = v[u].y = v[u].z = v[u].w = 0.0f;
                 if (kc + (uint32_t)part < ix.stride && row < nw)
-                    v = *reinterpret_cast<const float4*>(ix.points + (size_t)pids[row] * ix.stride + kc + part);
-                float* d = Cs + row * kGramPitch + part;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    v[u] = *reinterpret_cast<const float4*>(ix.points + (size_t)pids[row] * ix.stride + kc + part);
+            }
+        };
+        float4 pre[4];
+        fetch(0u, pre);
+        for (uint32_t kc = 0; kc < ix.stride; kc += kGramChunk) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = tid + 256 * u;
+                *reinterpret_cast<float4*>(Cs + (idx >> 3) * kGramPitch + ((idx & 7) << 2)) = pre[u];
             }
             block_sync();
-#pragma unroll 4
-            for (int kk = 0; kk < kGramChunk / 2; kk++) {
-                const int kcol = kk * 2 + (lane >> 5);
+            if (kc + kGramChunk < ix.stride) fetch(kc + kGramChunk, pre);
 #pragma unroll
-                for (int t = 0; t < 3; t++) {
-                    if (t < ntile && kTi[t] * 32 < nw) {
-                        const float av = Cs[(kTi[t] * 32 + (lane & 31)) * kGramPitch + kcol];
-                        const float bv = Cs[(kTj[t] * 32 + (lane & 31)) * kGramPitch + kcol];
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            for (int t = 0; t < 3; t++) {
+                if (t < ntile && kTi[t] * 32 < nw) {
+                    const float* ap = Cs + (kTi[t] * 32 + (lane & 31)) * kGramPitch + 16 * (lane >> 5);
+                    const float* bp = Cs + (kTj[t] * 32 + (lane & 31)) * kGramPitch + 16 * (lane >> 5);
+                    float4 af[4], bf[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        af[q] = *reinterpret_cast<const float4*>(ap + 4 * q);
+                        bf[q] = *reinterpret_cast<const float4*>(bp + 4 * q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[q].x, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bf[q].y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bf[q].z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bf[q].w, acc[t], 0, 0, 0);
                     }
                 }
             }

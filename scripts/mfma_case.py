@@ -1,20 +1,27 @@
 """C4 distance path under the profiler: exact 10-NN of 4096 queries against 1M x 768 through the
-f32-MFMA -2QP^T filter (mfma_dist_kernel) + canonical re-rank."""
+f32-MFMA -2QP^T filter (mfma_dist_kernel) + canonical re-rank.  usage: python scripts/mfma_case.py   (GPU box)"""
+import json
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import instant_distance_amd as ida  # noqa: E402
-from scripts.gpu_probe import gen  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
 
+import bench  # noqa: E402
+import instant_distance_amd as ida  # noqa: E402
+
+dev = torch.device("cuda", 0)
 n, dim, nq = 1_000_000, 768, 4096
-pts = gen(np.random.default_rng(1), n, dim, "lowrank")
-q = gen(np.random.default_rng(2), nq, dim, "lowrank")
+pts = bench.synth(torch, n, dim, 1, dev).cpu().numpy()
+q = bench.synth(torch, nq, dim, 2, dev).cpu().numpy()
 h = ida.Hnsw.from_parts(pts, np.full((n, 64), 0xFFFFFFFF, np.uint32), [], ida.Builder())
 os.environ["IDIST_BRUTEFORCE"] = "mfma"
 for _ in range(3):
     t = time.time(); pid, d = h.bruteforce(q, 10); dt = time.time() - t
-print("mfma bruteforce", nq, "x", n, "x", dim, "wall_s", round(dt, 4), "flop", 2.0 * nq * n * h.info().row_stride * (1 + 32768 / n))
+stride = h.info().row_stride
+print(json.dumps({"case": "mfma bruteforce", "nq": nq, "n": n, "dim": dim, "wall_s": round(dt, 4),
+                  "flop_filter_pass": 2.0 * nq * n * stride, "flop_sample_pass": 2.0 * nq * 32768 * stride}))

@@ -2,7 +2,7 @@
 idist_search_batch(nq = 1) calls on ONE shared C3 index — aggregate calls/s under runtime settings that decide whether
 the one-workgroup kernels of different streams overlap: hardware queues (GPU_MAX_HW_QUEUES), the timing events around
 each launch.  Every variant runs in its own process (the settings are read when the HIP runtime starts).
-usage: python scripts/probe_r03_threads.py out.jsonl"""
+usage: python scripts/probe_r03_threads.py out.jsonl [variant,variant,...]"""
 import json
 import os
 import subprocess
@@ -31,10 +31,13 @@ if os.environ.get("PB_CHILD"):
     sys.exit(0)
 
 fo = open(sys.argv[1], "a")
-VARIANTS = [("default", {}), ("hwq8", {"GPU_MAX_HW_QUEUES": "8"}), ("hwq16", {"GPU_MAX_HW_QUEUES": "16"}),
+VARIANTS = [("default", {}), ("hwq4", {"GPU_MAX_HW_QUEUES": "4"}), ("hwq8", {"GPU_MAX_HW_QUEUES": "8"}), ("hwq16", {"GPU_MAX_HW_QUEUES": "16"}),
             ("no_events", {"IDIST_KERNEL_EVENTS": "0"}), ("no_events_hwq16", {"IDIST_KERNEL_EVENTS": "0", "GPU_MAX_HW_QUEUES": "16"}),
             ("no_events_hwq32_staged", {"IDIST_KERNEL_EVENTS": "0", "GPU_MAX_HW_QUEUES": "32", "IDIST_NO_ZERO_COPY": "1"})]
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 for name, env in VARIANTS:
+    if only and name not in only:
+        continue
     e = dict(os.environ, PB_CHILD=name, **env)
     r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=e, capture_output=True, text=True, timeout=600)
     rows = [l[4:] for l in r.stdout.splitlines() if l.startswith("ROW ")]

@@ -16,8 +16,8 @@ INVALID = 0xFFFFFFFF
 # frozen at 7/8); IDIST_VISITED=bitmap selects the bitmap + Bloom-filter walks (classic / latency / overlap by batch
 # width and IDIST_WALK).  All must give the reference's results.
 SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by index size and ef_search)", {}),
-                   ("on-chip", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip"}),
-                   ("four waves per query", {"IDIST_QUAD_NQ": "4000000000"}),
+                   ("on-chip, quotient set", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "q16"}),
+                   ("four waves per query, quotient set", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_FORMAT": "q16"}),
                    ("four waves per query, set of 128 ids then bitmap", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_LOG2": "7"}),
                    ("on-chip classic", {"IDIST_WALK": "classic", "IDIST_VISITED": "onchip"}),
                    ("on-chip, full ids", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "ids"}),
