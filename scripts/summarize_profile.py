@@ -90,11 +90,31 @@ try:
                                 "timed_launches": len(timed)}
 except Exception as e:  # noqa: BLE001
     res["agreement_error"] = str(e)
+# L2 (TCC) view of the search kernel's full-batch launches: hit rate, reads that left the L2 for the fabric (EA), and how many
+# of those were addressed to the DRAM controllers.  The Infinity Cache (MALL) sits BEHIND the fabric port: its hits are part
+# of both EA counters, rocprofv3 on this build lists no MALL counter, so "fabric bytes" is an upper bound of DRAM bytes.
+tcc = defaultdict(lambda: defaultdict(list))
+for f in dbs("pmc_tcc"):
+    cur = sqlite3.connect(f).cursor()
+    for k, c, v in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+        if short(k):
+            tcc[short(k)][c].append(v)
+if tcc.get("search_kernel"):
+    t = {c: v[-1] for c, v in tcc["search_kernel"].items()}           # the last launch is a full 10k-query batch
+    hit, miss = t.get("TCC_HIT_sum", 0.0), t.get("TCC_MISS_sum", 0.0)
+    rd, rdd = t.get("TCC_EA0_RDREQ_sum", 0.0), t.get("TCC_EA0_RDREQ_DRAM_sum", 0.0)
+    res["l2_and_fabric"] = {"kernel": "search_kernel (last full-batch launch)", "TCC_HIT": hit, "TCC_MISS": miss,
+                            "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None,
+                            "EA_read_requests": rd, "EA_read_requests_to_DRAM_controllers": rdd,
+                            "share_of_fabric_reads_addressed_to_DRAM": round(rdd / rd, 4) if rd else None,
+                            "mall_note": "Infinity-Cache hits are inside both EA counters (the MALL sits behind the fabric port) and "
+                                         "rocprofv3 lists no MALL counter on gfx950: FETCH_SIZE is fabric bytes, an upper bound of DRAM bytes"}
 sf, sw = res["pmc_FETCH_SIZE"].get("search_kernel"), res["pmc_WRITE_SIZE"].get("search_kernel")
 if sf and sw and factor:
     fetch = sf["last_KB"] * 1024 * factor
     write = sw["last_KB"] * 1024
-    res["traffic"] = {"search_kernel_fetch_bytes_raw": sf["last_KB"] * 1024, "search_kernel_fetch_bytes_corrected": round(fetch),
+    res["traffic"] = {"config": res.get("bench", {}).get("config", {}).get("name", "C3"), "mall": res.get("l2_and_fabric"),
+                      "search_kernel_fetch_bytes_raw": sf["last_KB"] * 1024, "search_kernel_fetch_bytes_corrected": round(fetch),
                       "search_kernel_write_bytes": round(write), "search_kernel_hbm_bytes_per_launch": round(fetch + write)}
     if "bench" in res:
         alg = res["bench"]["roofline"]["alg_bytes_per_launch"]
@@ -118,7 +138,9 @@ if dest:
         f.write("\n## PMC (per dispatch, KB as reported)\n\n```\nFETCH_SIZE " + json.dumps(res["pmc_FETCH_SIZE"], indent=1) +
                 "\nWRITE_SIZE " + json.dumps(res["pmc_WRITE_SIZE"], indent=1) + "\n```\n")
         f.write("\n## FETCH_SIZE calibration on the gather pattern\n\n```\n" + json.dumps(res.get("calibration", {}), indent=1) + "\n```\n")
-        f.write("\n## search_kernel HBM traffic per launch\n\n```\n" + json.dumps(res.get("traffic", {}), indent=1) + "\n```\n")
+        f.write("\n## search_kernel fabric traffic per launch (FETCH_SIZE counts Infinity-Cache hits too)\n\n```\n" + json.dumps(res.get("traffic", {}), indent=1) + "\n```\n")
+        if "l2_and_fabric" in res:
+            f.write("\n## L2 hit rate and fabric reads of the search kernel\n\n```\n" + json.dumps(res["l2_and_fabric"], indent=1) + "\n```\n")
         if "agreement" in res:
             f.write("\n## search_kernel duration: rocprofv3 trace vs bench.py's own HIP events (the traced run)\n\n```\n" +
                     json.dumps(res["agreement"], indent=1) + "\n```\n(clock state moves the kernel time by several % between "
