@@ -32,6 +32,7 @@ CASES = {
     "onestream": {"IDIST_BUILD_PIPELINE": "0"},
     "onestream_r256": {"IDIST_BUILD_PIPELINE": "0", "IDIST_BUILD_A_REGS": "256"},
     "a2tile": {"IDIST_BUILD_A2": "tile"},
+    "chunk4": {"IDIST_BUILD_CHUNK": "4"},
     "default2": {},
 }
 names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(CASES)

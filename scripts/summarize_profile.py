@@ -9,6 +9,7 @@ from collections import defaultdict
 
 out = sys.argv[1]
 dest = sys.argv[2] if len(sys.argv) > 2 else None
+what = sys.argv[3] if len(sys.argv) > 3 else "`python bench.py` (C3: 1M x 300-d, 10k queries, ef_search=100)"
 res = {}
 KEYS = ("search_kernel", "build_insert_kernel", "build_select_mfma_kernel", "build_edge_dist_kernel", "copy_rows_kernel", "build_select_kernel", "build_update_fast_kernel", "build_update_simple_kernel", "build_update_kernel",
         "bruteforce_kernel", "distance_batch_kernel", "mfma_dist_kernel", "rerank_kernel", "kth_threshold_kernel",
@@ -126,8 +127,8 @@ if dest:
     if "traffic" in res:
         json.dump(res["traffic"], open(os.path.join(os.path.dirname(dest), "traffic_" + os.path.basename(dest).split("_")[-1] + ".json"), "w"), indent=1)
     with open(dest + ".md", "w") as f:
-        f.write(f"# rocprofv3 summary ({os.path.basename(dest)})\n\nCommand: `python bench.py` (C3: 1M x 300-d, 10k queries, ef_search=100) under "
-                "`rocprofv3 --kernel-trace --stats`, then separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes.\n\n")
+        f.write(f"# rocprofv3 summary ({os.path.basename(dest)})\n\nCommand: {what} under "
+                "`rocprofv3 --kernel-trace --stats`" + (", then separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / TCC passes" if res["pmc_FETCH_SIZE"] else "") + ".\n\n")
         f.write("## kernel-trace --stats (top kernels)\n\n| kernel | calls | total µs | avg µs | % |\n|---|---|---|---|---|\n")
         for r in res.get("kernel_stats", []):
             f.write(f"| `{r['kernel'][:70]}` | {r['calls']} | {r['total_us']} | {r['avg_us']} | {r['pct']} |\n")
