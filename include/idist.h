@@ -31,6 +31,7 @@
  *                           bitmap; the build clamps it to >= 8); also forces the on-chip walk
  *   IDIST_TAB_FORMAT=ids|q16  the on-chip visited set always keeps full ids (4 per bucket, frozen at 7/8) / 16-bit quotients
  *                           (8 per bucket, single ids overflow) wherever they apply, whatever the policy says
+ *   IDIST_TIE_SPILL=1       strict ties take the HBM bags at the first overflow instead of growing the LDS region first
  *   IDIST_BUILD_A_REGS=512  descents with one 512-register wave per SIMD instead of 256-register waves
  *   IDIST_QUAD_NQ=<n>       batches of <= n queries run four waves per query (default two queries per CU; 0 = never)
  *   IDIST_LATENCY_NQ=<n>    bitmap walk only: batches of <= n queries run its latency variant (default 1024)
@@ -110,7 +111,10 @@ typedef struct idist_config {
                                    it by itself: a build that overflows is repeated with 8x the region, a
                                    host-pointer search batch with 4x (the device-pointer variant reports the
                                    overflow through idist_search_ctx_status and uses the larger region from the
-                                   next launch on); only beyond 4096 entries is the error final. */
+                                   next launch on); beyond 4096 entries the ties that do not fit go to a bag in HBM
+                                   (n keys per query slot, as many slots as fit 1 GiB) and come back in (distance, pid)
+                                   order — unbounded like the reference's BinaryHeap (core/lib.rs:564), slow only on
+                                   data that needs it. */
 } idist_config;
 
 typedef struct idist_index idist_index;

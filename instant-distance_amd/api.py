@@ -99,15 +99,17 @@ class Builder:
         return self
 
     def tie_policy(self, policy: int) -> "Builder":
-        """TIES_STRICT (default): more than 64 un-expanded candidates exactly at the furthest distance raise
-        IdistError(6) — a result is the reference's or an error.  TIES_DROP: keep the 64 nearest, go on
+        """TIES_STRICT (default): results are the reference's whatever the number of un-expanded candidates exactly at
+        the furthest distance (the tie region grows, then spills to HBM; IdistError(6) only reaches callers of the
+        device-pointer API, whose next launch has the room).  TIES_DROP: keep the 64 nearest, go on
         (mass-duplicate data; deterministic, flagged in build_stats().tie_overflow / Search.tie_overflowed())."""
         self._tie_policy = int(policy)
         return self
 
     def tie_capacity(self, n: int) -> "Builder":
-        """Entries of the tie region behind `nearest` (0 = 64, at most 4096): raise it for data with masses of
-        exactly equal distances (dense integer grids) to stay bit-identical to the reference there."""
+        """Entries of the LDS tie region behind `nearest` (0 = 64, at most 4096).  Strict builds / searches enlarge it
+        by themselves and spill to HBM beyond 4096, so this only pre-sizes it for data with masses of exactly equal
+        distances (dense integer grids)."""
         self._tie_capacity = int(n)
         return self
 

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <time.h>
 #include <vector>
 
 using namespace idist;
@@ -179,6 +180,9 @@ struct Knobs {
     uint32_t tab_log2 = 0;        // IDIST_TAB_LOG2=<5..13>: size of the on-chip visited set (test knob: small sets exercise the overflow path)
     bool vis_bitmap = false;      // IDIST_VISITED=bitmap: search with bitmap + Bloom filter (16 waves per CU) instead of the on-chip set
     bool vis_onchip = false;      // IDIST_VISITED=onchip: the on-chip set whatever the policy says (test / A-B knob)
+    bool sync_flag = true;        // IDIST_SYNC=stream: narrow host-pointer calls wait with hipStreamSynchronize instead of for the completion
+                                  // word the kernel writes to the context's pinned buffer (A/B knob)
+    bool tie_spill_first = false; // IDIST_TIE_SPILL=1: strict ties go to the HBM bags at the first overflow instead of growing the LDS region first (test knob)
     bool events = true;           // IDIST_KERNEL_EVENTS=0: no HIP events around the search kernels (idist_search_ctx_kernel_times then has nothing)
     bool tab_ids = false;         // IDIST_TAB_FORMAT=ids: the on-chip set always keeps full ids (4 per bucket, frozen at 7/8), never
                                   // 16-bit quotients (8 per bucket, single ids overflow) (test / A-B knob)
@@ -198,6 +202,8 @@ struct Knobs {
         if (const char* e = getenv("IDIST_NO_ZERO_COPY")) k.no_zero_copy = e[0] != '0';
         if (const char* e = getenv("IDIST_TAB_FORMAT")) { k.tab_ids = e[0] == 'i'; k.tab_q16 = e[0] == 'q'; }
         if (const char* e = getenv("IDIST_KERNEL_EVENTS")) k.events = e[0] != '0';
+        if (const char* e = getenv("IDIST_TIE_SPILL")) k.tie_spill_first = e[0] == '1';
+        if (const char* e = getenv("IDIST_SYNC")) k.sync_flag = e[0] != 's';
         if (const char* e = getenv("IDIST_TAB_LOG2")) k.tab_log2 = std::min(13u, std::max(5u, (uint32_t)atoi(e)));
         return k;
     }
@@ -218,7 +224,9 @@ struct idist_search_ctx {
     uint8_t* h_io = nullptr;       // host address
     uint8_t* d_io = nullptr;       // the same memory as the device sees it
     size_t io_cap = 0;             // bytes of that buffer: 64 KB on first use, grown on demand up to kIoMaxBytes
-    static constexpr size_t kIoMinBytes = 64 * 1024, kIoMaxBytes = 256 * 1024, kIoStatusSlots = 256;   // ~100 queries: beyond that the staged copies are as fast (profiles/probe_r02_quad_single_query_phases.jsonl)
+    uint32_t done_seq = 0;         // completion word of the last narrow host-pointer launch (h_io + kIoStatusSlots * 4)
+    double call_ns_ema = 0.0;      // how long such a call has taken lately: the host sleeps through the first half of it
+    static constexpr size_t kIoMinBytes = 64 * 1024, kIoMaxBytes = 256 * 1024, kIoStatusSlots = 256, kIoHeadBytes = kIoStatusSlots * 4 + 64;   // ~100 queries: beyond that the staged copies are as fast (profiles/probe_r02_quad_single_query_phases.jsonl)
     hipStream_t stream = nullptr;
     hipEvent_t ev0[IDIST_EVENT_RING] = {nullptr}, ev1[IDIST_EVENT_RING] = {nullptr};
     uint64_t n_launch = 0;
@@ -232,6 +240,11 @@ struct idist_search_ctx {
     size_t cap_q = 0, cap_out = 0, cap_nq = 0;
     bool tie_overflowed = false;
     uint32_t tie_cap = 0;          // tie capacity this context escalated to (0 = the index's)
+    // strict ties, last resort: one bag of n keys per slot in HBM (the reference's candidate heap is unbounded, core/lib.rs:564)
+    bool tie_spill = false;        // later launches attach the bags
+    bool tie_escalation_exhausted = false;
+    uint64_t* d_tie_spill = nullptr;
+    uint32_t spill_slots = 0, n_points = 0;
     // copies of what idist_search_ctx_status needs, so that it never reads through `idx`
     int32_t tie_policy = IDIST_TIES_STRICT;
     uint32_t base_tie_cap = kTieCap, stride = 0, last_ef = 0;
@@ -348,7 +361,7 @@ idist_status device_status_to_code(uint32_t st, int32_t tie_policy) {
 }
 
 // ---- build driver: the per-layer insertion schedule of Hnsw::new, core/lib.rs:304-329 ----
-idist_status run_build(idist_index* ix, idist_progress* prog) {
+idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     const uint32_t n = ix->n;
     if (prog) { prog->total = n; prog->slot[0] = n ? 1 : 0; prog->slot[1] = 0; }   // pid 0 is in from the start
     if (n <= 1) return IDIST_OK;   // pid 0 is never inserted (core/lib.rs:279-280)
@@ -359,8 +372,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     // core/lib.rs:649 vs :438), one whole insertion per launch in program order — always the sequential schedule
     const bool ext = cfg.has_heuristic && cfg.extend_candidates;
     const uint32_t cap = ext ? 1u : std::min<uint32_t>(cfg.max_batch == 0 ? 8192u : cfg.max_batch, std::max<uint32_t>(1u, n / 32u));
-    // the descents keep their visited set on chip, one fat wave per SIMD (up to 8 per CU with the 16-KB quotient set)
-    const uint32_t slots = std::min(cap, (uint32_t)ix->n_cu * 8u);
+    // the descents keep their visited set on chip, one fat wave per SIMD (up to 8 per CU with the 16-KB quotient set);
+    // with the HBM tie bags (one of n keys per slot) as many slots as fit 1 GiB
+    uint32_t slots = std::min(cap, (uint32_t)ix->n_cu * 8u);
+    if (tie_spill) slots = std::min<uint32_t>(slots, (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)n * 8)));
     const VisGeom vg = vis_geometry(n);
     const Knobs knobs = Knobs::from_env();
     const uint32_t tie_cap = tie_capacity(cfg);
@@ -417,6 +432,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
                          !(getenv("IDIST_BUILD_A2") && getenv("IDIST_BUILD_A2")[0] == 't');
     const size_t smemA2m = smem_bytes_select_mfma(ix->L.stride);
     uint32_t* d_vis = nullptr;
+    uint64_t* d_tie_spill = nullptr;
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
     uint32_t* d_small = nullptr;           // [0] n_touched, [1..6] queue (A, B, n_slow, B2, A2, A3), [8] status
@@ -455,7 +471,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
         if (s2) hipStreamDestroy(s2);
         for (int i = 0; i < 2; i++) { if (evA[i]) hipEventDestroy(evA[i]); if (evS[i]) hipEventDestroy(evS[i]); }
         hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount); hipFree(d_dlog_log); hipFree(d_dlog_pd);
-        hipFree(d_vis); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
+        hipFree(d_vis); hipFree(d_tie_spill); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
         if (e0) hipEventDestroy(e0);
         if (e1) hipEventDestroy(e1);
@@ -471,6 +487,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     if (ext) BCHK(hipMalloc((void**)&d_ext_work, (size_t)ext_cap * 8));
     BCHK(hipMalloc((void**)&d_vis, (size_t)slots * vg.slot_words * 4));
     BCHK(hipMemset(d_vis, 0, (size_t)slots * vg.slot_words * 4));
+    if (tie_spill) BCHK(hipMalloc((void**)&d_tie_spill, (size_t)slots * n * 8));
     BCHK(hipMalloc((void**)&d_nbr_dist, (size_t)n * IDIST_M2 * 4));
     BCHK(hipMemset(d_nbr_dist, 0, (size_t)n * IDIST_M2 * 4));
     BCHK(hipMalloc((void**)&d_nbr_aux, (size_t)n * IDIST_M2 * 4));
@@ -539,6 +556,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog) {
     a.wcount = d_wcount;
     a.rt2 = rt2;
     a.tie_cap = tie_cap;
+    a.tie_spill = d_tie_spill;
+    a.tie_spill_cap = tie_spill ? n : 0u;
     if (const char* e = getenv("IDIST_BUILD_CHUNK")) a.chunk = (uint32_t)atoi(e);
     const size_t smemF = smem_bytes_update_fast(ix->L.stride);
     const bool classic = knobs.classic;
@@ -721,17 +740,21 @@ idist_status build_common(const void* points, bool on_device, uint32_t n, uint32
     idist_progress* prog = g_watch;
     g_watch = nullptr;
     idist_config c = *cfg;
+    const bool spill_first = getenv("IDIST_TIE_SPILL") && getenv("IDIST_TIE_SPILL")[0] == '1';   // test knob, see Knobs
+    bool tie_spill = false;
     for (;;) {
         idist_index* ix = nullptr;
         CHK(index_alloc(n, dim, &c, cum + 1, n ? nl - 1 : 0, device, &ix));
         idist_status s = on_device ? load_points_device(ix, (const float*)points) : load_points_host(ix, (const float*)points);
-        if (s == IDIST_OK) s = run_build(ix, prog);
+        if (s == IDIST_OK) s = run_build(ix, prog, tie_spill);
         if (s == IDIST_OK) { *out = ix; return IDIST_OK; }
         idist_index_free(ix);
-        // strict ties: the descent's tie region was too small -> build again with a larger one (x8, at most 4096)
+        // strict ties: the descent's tie region was too small -> build again with a larger one (x8, at most 4096 entries of
+        // LDS), and when that is not enough either, with HBM bags behind it (unbounded, like the reference's heap)
         const uint32_t cap = tie_capacity(c);
-        if (s != IDIST_ERR_TIE_OVERFLOW || cap >= 4096u) return s;
-        c.tie_capacity = std::min<uint32_t>(4096u, cap * 8u);
+        if (s != IDIST_ERR_TIE_OVERFLOW || tie_spill) return s;
+        if (cap >= 4096u || spill_first) tie_spill = true;
+        else c.tie_capacity = std::min<uint32_t>(4096u, cap * 8u);
     }
 }
 
@@ -776,7 +799,7 @@ constexpr size_t kCacheResidentBytes = (size_t)128 << 20;
 
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
                            uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream,
-                           uint32_t* status_host = nullptr, uint32_t* grid_out = nullptr) {
+                           uint32_t* status_host = nullptr, uint32_t* grid_out = nullptr, uint32_t* done_host = nullptr, uint32_t done_seq = 0) {
     const uint32_t ef = ix->cfg.ef_search;
     SearchArgs a{};
     a.queries = d_q;
@@ -817,6 +840,21 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
 #ifdef IDIST_TUNE
     if (const char* e = getenv("IDIST_WAVES_PER_CU")) resident = (uint32_t)ix->n_cu * (uint32_t)std::max(1, atoi(e));   // tuning builds only
 #endif
+    if (ctx->tie_spill) {
+        // one bag of n keys per slot (a walk can hold every point as a tie at most once); the slots that fit 1 GiB
+        const uint32_t fit = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)std::max(ix->n, 1u) * 8));
+        resident = std::min(resident, fit);
+        if (!ctx->d_tie_spill || ctx->spill_slots < std::min(nq, resident)) {
+            HIPCHK(hipDeviceSynchronize());
+            hipFree(ctx->d_tie_spill);
+            ctx->d_tie_spill = nullptr;
+            ctx->spill_slots = std::min(std::max(nq, 1u), resident);
+            HIPCHK(hipMalloc((void**)&ctx->d_tie_spill, (size_t)ctx->spill_slots * std::max(ix->n, 1u) * 8));
+        }
+        resident = std::min(resident, ctx->spill_slots);
+        a.tie_spill = ctx->d_tie_spill;
+        a.tie_spill_cap = ix->n;
+    }
     CHK(ensure_slots(ctx, std::min(nq, resident), stream));
     ctx->last_ef = ef;
     a.out_pid = d_pid;
@@ -838,6 +876,9 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     IndexView view = ix->view();
     a.queue_base = ctx->queue_base;
     a.status_host = status_host && grid <= idist_search_ctx::kIoStatusSlots ? status_host : nullptr;
+    a.done_host = done_host;
+    a.done_count = ctx->d_next + 2;
+    a.done_seq = done_seq;
     if (grid_out) *grid_out = grid;
     const uint32_t slot = (uint32_t)(ctx->n_launch % IDIST_EVENT_RING);
     if (ctx->knobs.events) HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
@@ -1170,6 +1211,7 @@ idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_
     c->knobs = Knobs::from_env();
     c->tie_policy = idx->cfg.tie_policy;
     c->base_tie_cap = tie_capacity(idx->cfg);
+    c->n_points = idx->n;
     c->stride = idx->L.stride;
     auto bail = [&](hipError_t e) {
         idist_search_ctx_free(c);
@@ -1196,6 +1238,7 @@ void idist_search_ctx_free(idist_search_ctx* c) {
     if (!c) return;
     // (the index may already be gone: nothing of it is touched here)
     hipFree(c->d_visited);
+    hipFree(c->d_tie_spill);
     hipFree(c->d_next);
     if (c->h_io) hipHostFree(c->h_io);
     hipFree(c->d_q);
@@ -1244,11 +1287,16 @@ idist_status idist_search_ctx_status(idist_search_ctx* ctx) {
     if (st) HIPCHK(hipMemset(ctx->d_next + 1, 0, 4));
     if (st & kStTieOverflow) {
         ctx->tie_overflowed = true;
-        // strict: later launches of this context get a larger tie region (x4, at most 4096 entries, LDS permitting)
+        // strict: later launches of this context get a larger tie region (x4, at most 4096 entries, LDS permitting); when that
+        // is exhausted, HBM bags that take whatever the region cannot (unbounded, like the reference's heap)
         const uint32_t cap = std::max(ctx->base_tie_cap, ctx->tie_cap), next = std::min<uint32_t>(4096u, cap * 4u);
-        if (ctx->tie_policy == IDIST_TIES_STRICT && next > cap &&
-            smem_bytes(ctx->stride, ctx->last_ef + 64 + next + 8, false, kBloomWords, ctx->vis.dirty_words) <= 64 * 1024)
-            ctx->tie_cap = next;
+        if (ctx->tie_policy == IDIST_TIES_STRICT) {
+            if (!ctx->knobs.tie_spill_first && next > cap &&
+                smem_bytes(ctx->stride, ctx->last_ef + 64 + next + 8, false, kBloomWords, ctx->vis.dirty_words) <= 64 * 1024)
+                ctx->tie_cap = next;
+            else if (!ctx->tie_spill) ctx->tie_spill = true;
+            else ctx->tie_escalation_exhausted = true;
+        }
         g_tie_cap_msg = cap;
     }
     return device_status_to_code(st, ctx->tie_policy);
@@ -1301,7 +1349,7 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
     // Narrow batches — the reference's call is ONE query per Hnsw::search: query and results cross PCIe through one
     // pinned, device-mapped buffer that the kernel reads and writes itself; the call is a host memcpy, one launch, one
     // stream sync, a host memcpy.  (The general path below costs six copy / memset calls of ~10 us each around the kernel.)
-    const size_t io_need = qb + 2 * ob + (size_t)nq * 16 + idist_search_ctx::kIoStatusSlots * 4;
+    const size_t io_need = qb + 2 * ob + (size_t)nq * 16 + idist_search_ctx::kIoHeadBytes;
     if (io_need <= idist_search_ctx::kIoMaxBytes && !ctx->knobs.no_zero_copy) {
         if (io_need > ctx->io_cap) {
             size_t cap = idist_search_ctx::kIoMinBytes;
@@ -1316,7 +1364,8 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
         }
         uint8_t* hp = ctx->h_io;
         uint32_t* h_status = (uint32_t*)hp;                                   // [256]
-        float* h_q = (float*)(hp + idist_search_ctx::kIoStatusSlots * 4);
+        volatile uint32_t* h_done = (volatile uint32_t*)(hp + idist_search_ctx::kIoStatusSlots * 4);   // completion word
+        float* h_q = (float*)(hp + idist_search_ctx::kIoHeadBytes);
         uint32_t* h_pid = (uint32_t*)((uint8_t*)h_q + qb);
         float* h_dist = (float*)((uint8_t*)h_pid + ob);
         uint32_t* h_cnt = (uint32_t*)((uint8_t*)h_dist + ob);
@@ -1325,18 +1374,43 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
         for (;;) {
             memcpy(h_q, queries, qb);
             memset(h_status, 0, idist_search_ctx::kIoStatusSlots * 4);
+            *h_done = 0u;
             uint32_t grid = 0;
+            const bool flag = ctx->knobs.sync_flag;
+            const uint32_t seq = ++ctx->done_seq ? ctx->done_seq : ++ctx->done_seq;       // never 0: a fresh buffer reads 0
+            const auto t0 = std::chrono::steady_clock::now();
             CHK(launch_search(idx, ctx, (const float*)((uint8_t*)h_q + dv), nq, (uint32_t*)((uint8_t*)h_pid + dv),
                               (float*)((uint8_t*)h_dist + dv), (uint32_t*)((uint8_t*)h_cnt + dv),
                               out_counters ? (uint32_t*)((uint8_t*)h_ctr + dv) : nullptr, ctx->stream,
-                              (uint32_t*)((uint8_t*)h_status + dv), &grid));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+                              (uint32_t*)((uint8_t*)h_status + dv), &grid, flag ? (uint32_t*)((uint8_t*)h_done + dv) : nullptr, seq));
+            if (flag) {
+                // The kernel's last workgroup writes `seq` into the pinned buffer behind its results.  One Search per thread
+                // is the reference's model, so waiting must not burn a core per thread: sleep through the first half of what
+                // such a call has been taking, then poll the word; a stream synchronisation only if it stays away for 2 s.
+                if (ctx->call_ns_ema > 200e3) {
+                    struct timespec ts = {0, (long)(ctx->call_ns_ema * 0.5)};
+                    nanosleep(&ts, nullptr);
+                }
+                bool seen = false;
+                for (uint64_t spins = 0; !(seen = (*h_done == seq)); spins++) {
+                    __builtin_ia32_pause();
+                    if ((spins & 0xFFFFu) == 0xFFFFu &&
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                if (!seen) HIPCHK(hipStreamSynchronize(ctx->stream));
+                const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+                ctx->call_ns_ema = ctx->call_ns_ema == 0.0 ? ns : 0.8 * ctx->call_ns_ema + 0.2 * ns;
+            } else {
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+            }
             uint32_t any = grid <= idist_search_ctx::kIoStatusSlots ? 0u : 1u;  // too many workgroups for the slots: ask the device
             for (uint32_t g = 0; g < grid && g < idist_search_ctx::kIoStatusSlots; g++) any |= h_status[g];
             if (any) {
                 const uint32_t cap_before = std::max(tie_capacity(idx->cfg), ctx->tie_cap);
+                const bool spill_before = ctx->tie_spill;
                 const idist_status s = idist_search_ctx_status(ctx);
-                if (s == IDIST_ERR_TIE_OVERFLOW && std::max(tie_capacity(idx->cfg), ctx->tie_cap) > cap_before) continue;
+                if (s == IDIST_ERR_TIE_OVERFLOW && (std::max(tie_capacity(idx->cfg), ctx->tie_cap) > cap_before || ctx->tie_spill != spill_before)) continue;
                 if (s != IDIST_OK) return s;
             }
             memcpy(out_pid, h_pid, ob);
@@ -1371,8 +1445,9 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
         // strict ties: the tie region was too small -> idist_search_ctx_status enlarged it for this context; the
         // batch is simply searched again (queries are independent and the results are overwritten)
         const uint32_t cap_before = std::max(tie_capacity(idx->cfg), ctx->tie_cap);
+        const bool spill_before = ctx->tie_spill;
         const idist_status s = idist_search_ctx_status(ctx);
-        if (s == IDIST_ERR_TIE_OVERFLOW && std::max(tie_capacity(idx->cfg), ctx->tie_cap) > cap_before) continue;
+        if (s == IDIST_ERR_TIE_OVERFLOW && (std::max(tie_capacity(idx->cfg), ctx->tie_cap) > cap_before || ctx->tie_spill != spill_before)) continue;
         return s;
     }
 }

@@ -371,6 +371,12 @@ struct WState {
     int cursor;      // lower bound of the first un-expanded entry
     uint32_t status;
     int tie_cap = kTieCap;   // capacity of the tie region behind W[ef)
+    // Ties beyond that capacity (the reference's candidate heap is unbounded, core/lib.rs:564): an unsorted bag in HBM, all
+    // of one distance (spill_fd = the furthest distance they tie with).  Invariant: every tie kept in LDS is smaller than
+    // every key of the bag (spill_min), so the LDS region is popped first and refilled from the bag's smallest keys.
+    uint64_t* spill = nullptr;          // [spill_cap] or nullptr: ties that do not fit are an error / dropped (tie policy)
+    uint32_t spill_cap = 0, spill_n = 0, spill_fd = 0;
+    uint64_t spill_min = ~0ull;
 };
 
 // number of entries with (masked) key < k  == Vec::binary_search Err(idx), core/lib.rs:712
@@ -434,6 +440,7 @@ __device__ __forceinline__ void w_truncate(WState& st) {
     const int lane = lane_id();
     if (st.ef == 0) { st.plen = 0; st.cursor = 0; return; }
     const uint32_t fd = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32);
+    if (st.spill_n && fd != st.spill_fd) { st.spill_n = 0; st.spill_min = ~0ull; }   // the furthest distance fell: those ties are dead
     int out = st.ef;
     for (int i0 = st.ef; i0 < st.plen; i0 += 64) {
         const int i = i0 + lane;
@@ -449,9 +456,85 @@ __device__ __forceinline__ void w_truncate(WState& st) {
         wave_sync();
         out += __popcll(m);
     }
-    if (out - st.ef > st.tie_cap) { st.status |= kStTieOverflow; out = st.ef + st.tie_cap; }
+    int keep_lds = out - st.ef;
+    if (st.spill_n) {                                     // ties not below the bag's smallest key queue up behind it
+        int below = 0;
+        for (int i0 = st.ef; i0 < out; i0 += 64) {
+            const int i = i0 + lane;
+            below += __popcll(__ballot(i < out && st.W[i] < st.spill_min));   // (kept ties carry no flag)
+        }
+        keep_lds = below;
+    }
+    if (keep_lds > st.tie_cap) keep_lds = st.tie_cap;
+    const int n_mv = out - st.ef - keep_lds;
+    if (n_mv > 0) {
+        if (st.spill && st.spill_n + (uint32_t)n_mv <= st.spill_cap) {
+            const uint64_t first = st.W[st.ef + keep_lds];
+            for (int i = lane; i < n_mv; i += 64) st.spill[st.spill_n + (uint32_t)i] = st.W[st.ef + keep_lds + i];
+            st.spill_n += (uint32_t)n_mv;
+            st.spill_fd = fd;
+            if (first < st.spill_min) st.spill_min = first;
+        } else {
+            st.status |= kStTieOverflow;                  // no bag (or, impossibly, a full one): reported, never silent
+        }
+        out = st.ef + keep_lds;
+    }
     st.plen = out;
     if (st.cursor > st.ef) st.cursor = st.ef;
+}
+
+// The LDS tie region is exhausted and the bag is not: move the bag's tie_cap smallest keys into W[ef..) (sorted), close the
+// gap they leave.  Returns false if nothing could be refilled (the bag's ties died with the furthest distance).
+__device__ __forceinline__ bool w_refill_ties(WState& st) {
+    const int lane = lane_id();
+    if (st.plen < st.ef || st.ef == 0) { st.spill_n = 0; st.spill_min = ~0ull; return false; }
+    const uint32_t fd = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32);
+    if (fd != st.spill_fd) { st.spill_n = 0; st.spill_min = ~0ull; return false; }
+#ifndef IDIST_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the bag's own stores have landed before it is read back
+#endif
+    wave_sync();
+    WState ts{st.W + st.ef, 0, st.tie_cap, 0, 0u};
+    for (uint32_t base = 0; base < st.spill_n; base += 64u) {
+        const bool on = base + (uint32_t)lane < st.spill_n;
+        const uint64_t key = on ? st.spill[base + (uint32_t)lane] : kMaxKey;
+        const uint64_t thr = ts.plen >= ts.ef ? (ts.W[ts.ef - 1] & kKeyMask) : kMaxKey + 1ull;
+        uint64_t pm = __ballot(on && key < thr);
+        while (pm) {
+            const int i = __builtin_ctzll(pm);
+            pm &= pm - 1ull;
+            const uint64_t kk = bcast_u64(key, i);
+            const int idx = w_rank(ts, kk);
+            if (idx < ts.ef) w_insert(ts, idx, kk);
+            if (ts.plen > ts.ef) ts.plen = ts.ef;
+        }
+        wave_sync();
+    }
+    const int cnt = ts.plen;
+    if (cnt == 0) { st.spill_n = 0; st.spill_min = ~0ull; return false; }
+    const uint64_t thr = st.W[st.ef + cnt - 1];
+    uint32_t out = 0;
+    uint64_t mn = ~0ull;
+    for (uint32_t base = 0; base < st.spill_n; base += 64u) {
+        const bool on = base + (uint32_t)lane < st.spill_n;
+        const uint64_t key = on ? st.spill[base + (uint32_t)lane] : 0ull;
+        const bool keepk = on && key > thr;
+        const uint64_t m = __ballot(keepk);
+        // in place: out + |kept| <= base + 64, and this chunk already sits in registers
+        if (keepk) { st.spill[out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key; mn = key < mn ? key : mn; }
+        out += (uint32_t)__popcll(m);
+    }
+    for (int sh = 32; sh >= 1; sh >>= 1) {                 // wave minimum of the surviving keys
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mn, sh, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mn >> 32), sh, 64);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        mn = o < mn ? o : mn;
+    }
+    st.spill_n = out;
+    st.spill_min = out ? mn : ~0ull;
+    st.plen = st.ef + cnt;
+    st.cursor = st.ef;
+    wave_sync();
+    return true;
 }
 
 // Search::cull, core/lib.rs:729-737: candidates := nearest, visited := pids(nearest)
@@ -460,6 +543,8 @@ __device__ __forceinline__ void w_cull(WState& st) {
     if (st.plen > st.ef) st.plen = st.ef;
     for (int i = lane; i < st.plen; i += 64) st.W[i] &= kKeyMask;
     st.cursor = 0;
+    st.spill_n = 0;
+    st.spill_min = ~0ull;
     wave_sync();
 }
 
@@ -1098,7 +1183,8 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     for (;;) {
         [[maybe_unused]] const uint32_t tk0 = IDIST_TICK();
         [[maybe_unused]] bool tk_on = false;
-        const int ci = w_pop(st);                         // :599-604
+        int ci = w_pop(st);                               // :599-604
+        if (ci < 0 && st.spill_n && w_refill_ties(st)) ci = w_pop(st);   // live ties that did not fit the LDS region
         if (ci < 0) break;
         const uint64_t c = st.W[ci];
         wave_sync();

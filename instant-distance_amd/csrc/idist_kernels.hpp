@@ -139,6 +139,13 @@ struct SearchArgs {
     uint32_t tab_log2;      // log2(entries) of the on-chip visited set (walks with it): 4 << tab_log2 bytes of LDS
     uint32_t ubits;         // quotient form of that set: bits of the id universe, ceil(log2 n) (q16_* in idist_device.hpp)
     uint32_t tie_cap;       // capacity of the tie region (idist_config.tie_capacity)
+    uint64_t* tie_spill;    // [slots][tie_spill_cap] or null: HBM bags for the ties beyond that capacity (WState::spill)
+    uint32_t tie_spill_cap;
+    // narrow host-pointer calls: the last workgroup to finish writes done_seq to pinned host memory — the host waits for
+    // that word instead of a stream synchronisation (done_count: device word, back to zero when the launch ends)
+    uint32_t* done_host;
+    uint32_t* done_count;
+    uint32_t done_seq;
 };
 // the LDS tail region (after the dirty-block bitmap) holds the Bloom filter or the on-chip visited set
 __device__ __forceinline__ void visited_attach_tab(Visited& v, uint32_t* mem, uint32_t log2_entries) {
@@ -216,6 +223,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         wave_sync();
 
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
+        if (a.tie_spill) { st.spill = a.tie_spill + (size_t)slot * a.tie_spill_cap; st.spill_cap = a.tie_spill_cap; }
         Counters ctr{0, 0, 0};
         DistLog nolog{nullptr, 0u};
         // search.reset(), :357: the visited set was emptied when the slot's previous search ended
@@ -269,6 +277,14 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
     if (lane == 0 && status) {
         atomicOr(a.status, status);
         if (a.status_host) a.status_host[blockIdx.x] = status;
+    }
+    if (a.done_host) {
+        __threadfence_system();                                        // this workgroup's results and status are out
+        if (lane == 0 && atomicAdd(a.done_count, 1u) + 1u == gridDim.x) {
+            *a.done_count = 0u;                                        // (the context's next launch is ordered behind this one)
+            __threadfence_system();
+            *reinterpret_cast<volatile uint32_t*>(a.done_host) = a.done_seq;
+        }
     }
 }
 
@@ -401,6 +417,8 @@ struct BuildArgs {
     uint32_t rt2;               // step A2: same for the new point's own selection
     uint32_t chunk;             // step B: items per dequeue, 0 = by load (IDIST_BUILD_CHUNK, test knob)
     uint32_t tie_cap;           // capacity of the tie region of the descent (idist_config.tie_capacity)
+    uint64_t* tie_spill;        // [slots][tie_spill_cap] or null: HBM bags for the ties beyond that capacity (WState::spill)
+    uint32_t tie_spill_cap;
     uint32_t* queue;            // work queue heads: [0] step A, [1] step B, [3] step B2, [4] step A2 ([2] = n_slow)
     unsigned long long* stats;  // [16] n_dist n_exp0 n_expU n_sel_pairs n_heur_rows n_updates n_fast n_full n_heur_ref
     uint32_t* status;
@@ -498,6 +516,7 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
         if (item >= a.count) break;
         const uint32_t nw_pid = a.start + item;
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
+        if (a.tie_spill) { st.spill = a.tie_spill + (size_t)slot * a.tie_spill_cap; st.spill_cap = a.tie_spill_cap; }
         // only the heuristic's re-selections look distances up
         DistLog dl{a.has_heuristic && a.use_dlog ? a.dlog_log + ((size_t)item << a.dl_shift) : nullptr, 0u};
         insert_descent<NB, RS, TAIL, LAT>(ix, a, sm, st, vis, nw_pid, tot, dl);
@@ -672,6 +691,7 @@ __global__ __launch_bounds__(64) void build_extend_kernel(IndexView ix, BuildArg
     HeurCounters hc{0, 0};
     const uint32_t nw_pid = a.start;                                                 // one insertion per launch
     WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
+    if (a.tie_spill) { st.spill = a.tie_spill; st.spill_cap = a.tie_spill_cap; }
     DistLog nolog{nullptr, 0u};
     insert_descent<NB, RS, TAIL, LAT>(ix, a, sm, st, vis, nw_pid, tot, nolog);       // :442-461
     const int nn = st.plen < st.ef ? st.plen : st.ef;

@@ -655,3 +655,36 @@ def test_strict_ties_enlarge_the_region_on_demand(eng, oracle):
     zero, layers = hb.into_parts()
     assert np.array_equal(zero, oix.zero) and all(np.array_equal(x, y) for x, y in zip(layers, oix.layers))
     assert ida.Hnsw.from_ordered_points(pts, tiny().tie_policy(ida.TIES_DROP)).build_stats().tie_overflow == 1
+
+
+def test_strict_ties_spill_to_hbm(eng, oracle, monkeypatch):
+    """The reference's candidate heap is unbounded (core/lib.rs:564).  Ties that do not fit the LDS region — after it has
+    grown to 4096 entries, or at once with IDIST_TIE_SPILL=1 as here — go to a per-slot bag in HBM and come back in
+    (distance, pid) order: with a ONE-entry region on integer-grid data nearly every tie takes that road, and search (every
+    walk variant) and exact build must still be the oracle's, bit for bit."""
+    ida, kind = eng
+    monkeypatch.setenv("IDIST_TIE_SPILL", "1")
+    rng = np.random.default_rng(23)
+    n, ef = S(kind, 300, 8000), S(kind, 12, 60)
+    pts = rng.integers(0, 3, size=(n, 3)).astype(np.float32)
+    q = rng.integers(0, 3, size=(S(kind, 10, 200), 3)).astype(np.float32) + np.float32(0.5)   # cell centres: many equal distances
+    cfg = oracle.default_config(metric=1, ef_search=ef, ef_construction=ef)
+    oix = oracle.Index.build(pts, cfg)
+    want = oix.search(q)
+    tiny = lambda: ida.Builder().metric(1).ef_search(ef).ef_construction(ef).max_batch(1).tie_capacity(1)   # noqa: E731
+    hs = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, tiny())
+    for _, lat in pc.SEARCH_VARIANTS:
+        with pc.search_variant(lat):
+            s = ida.Search()
+            pc.check_search_result(hs.search_batch(q, s, counters=True), want)
+            pc.check_search_result(hs.search_batch(q[:3], s, counters=True), oix.search(q[:3]))   # the context keeps its bags
+    hb = ida.Hnsw.from_ordered_points(pts, tiny())
+    assert hb.info().tie_capacity == 1 and hb.build_stats().tie_overflow == 0     # no growth: the bags took the ties
+    zero, layers = hb.into_parts()
+    assert np.array_equal(zero, oix.zero) and all(np.array_equal(x, y) for x, y in zip(layers, oix.layers))
+    # squared L2 on a 2-d grid, default region (64): the 5-d grid of test_tie_policy needs the growth + bags on the GPU only
+    pts2 = pc.gen_points(rng, S(kind, 260, 6000), 2, "grid")
+    o2 = oracle.Index.build(pts2, oracle.default_config(ef_search=S(kind, 20, 100)))
+    h2 = ida.Hnsw.from_parts(pts2, o2.zero, o2.layers, ida.Builder().ef_search(S(kind, 20, 100)).tie_capacity(2))
+    q2 = pts2[: S(kind, 6, 100)] + np.float32(0.5)
+    pc.check_search_result(h2.search_batch(q2, ida.Search(), counters=True), o2.search(q2))
