@@ -126,6 +126,7 @@ def scalar_calls(hnsw, ida, q_host, n_threads, calls):
         t.join()
     if errs:
         raise RuntimeError(f"idist_search_batch failed in a thread: status {errs}")
+    scalar_calls.kernel_ms = float(np.mean([s.kernel_times_ms(32).mean() for s in searches]))   # HIP events of the last launches
     return n_threads * calls / dt
 
 
@@ -345,7 +346,8 @@ def main():
         # T host threads, one Search each, scalar calls on one shared index (core/lib.rs:352-356)
         thr = {}
         for T in [int(x) for x in args.threads.split(",") if x]:
-            thr[str(T)] = {"gpu_calls_per_s": round(scalar_calls(hnsw, ida, q_host, T, max(50, 1600 // T)), 1)}
+            thr[str(T)] = {"gpu_calls_per_s": round(scalar_calls(hnsw, ida, q_host, T, max(50, 1600 // T)), 1),
+                           "gpu_kernel_ms_mean": round(scalar_calls.kernel_ms, 4)}
         single["threads"] = thr
         hnsw.search_batch(q_host, search)
         t0 = time.perf_counter()

@@ -31,6 +31,7 @@
  *                           bitmap; the build clamps it to >= 8); also forces the on-chip walk
  *   IDIST_TAB_FORMAT=ids|q16  the on-chip visited set always keeps full ids (4 per bucket, frozen at 7/8) / 16-bit quotients
  *                           (8 per bucket, single ids overflow) wherever they apply, whatever the policy says
+ *   IDIST_SYNC=stream       narrow host-pointer calls wait with hipStreamSynchronize instead of for the kernel's completion word
  *   IDIST_TIE_SPILL=1       strict ties take the HBM bags at the first overflow instead of growing the LDS region first
  *   IDIST_BUILD_A_REGS=512  descents with one 512-register wave per SIMD instead of 256-register waves
  *   IDIST_QUAD_NQ=<n>       batches of <= n queries run four waves per query (default two queries per CU; 0 = never)
