@@ -31,6 +31,7 @@
  *                           bitmap; the build clamps it to >= 8); also forces the on-chip walk
  *   IDIST_TAB_FORMAT=ids|q16  the on-chip visited set always keeps full ids (4 per bucket, frozen at 7/8) / 16-bit quotients
  *                           (8 per bucket, single ids overflow) wherever they apply, whatever the policy says
+ *   IDIST_COMBINE=0         every scalar host-pointer call makes its own launch (no riding along in another thread's launch)
  *   IDIST_SYNC=stream       narrow host-pointer calls wait with hipStreamSynchronize instead of for the kernel's completion word
  *   IDIST_TIE_SPILL=1       strict ties take the HBM bags at the first overflow instead of growing the LDS region first
  *   IDIST_BUILD_A_REGS=512  descents with one 512-register wave per SIMD instead of 256-register waves
@@ -237,7 +238,8 @@ void idist_search_ctx_free(idist_search_ctx* ctx);
 idist_status idist_search_ctx_reserve(idist_search_ctx* ctx, uint32_t slots);
 
 /* Hnsw::search, core/lib.rs:352-383, for nq queries at once (nq == 1 backs the scalar
- * call).  Results are Search.nearest: <= ef_search (pid, distance) pairs, nearest first
+ * call; scalar calls from many threads — one context each, the reference's `&mut Search` per thread — are combined into
+ * few launches once more than eight are in flight on the index: same results, higher aggregate rate).  Results are Search.nearest: <= ef_search (pid, distance) pairs, nearest first
  * (the caller's `.take(k)` is a prefix).  out_pid/out_dist: nq*ef_search, padded with
  * IDIST_INVALID / +inf; out_count: nq; out_counters (optional): nq*3
  * {n_dist, n_exp0, n_expU} per query.  Host pointers; blocks until done. */

@@ -4,6 +4,7 @@
 #include "../../include/idist.h"
 #include "idist_kernels.hpp"
 #include "idist_mfma.hpp"
+#include "idist_combine.hpp"
 
 #ifndef IDIST_EMU
 #include <hip/hip_runtime.h>
@@ -16,6 +17,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -132,8 +135,22 @@ idist_status validate_config(const idist_config* cfg, bool for_build) {
 
 }  // namespace
 
+// one scalar Hnsw::search call waiting to be served, alone or as part of another thread's launch (idist_combine.hpp)
+struct ScalarReq {
+    const float* q;
+    uint32_t* pid;
+    float* dist;
+    uint32_t* cnt;
+    uint32_t* ctr;
+    idist_status st = IDIST_OK;
+    std::string err;
+    bool done = false, lead = false;
+    std::condition_variable cv;
+};
+
 struct idist_index {
     uint64_t uid = 0;            // never reused: a context is bound to (pointer, uid), not to the pointer alone
+    mutable idist::Combiner<ScalarReq> comb;   // scalar calls of many threads -> few launches (the index is shared, `&self`)
     int32_t device = 0;
     idist_config cfg{};
     uint32_t n = 0, dim = 0;
@@ -180,6 +197,7 @@ struct Knobs {
     uint32_t tab_log2 = 0;        // IDIST_TAB_LOG2=<5..13>: size of the on-chip visited set (test knob: small sets exercise the overflow path)
     bool vis_bitmap = false;      // IDIST_VISITED=bitmap: search with bitmap + Bloom filter (16 waves per CU) instead of the on-chip set
     bool vis_onchip = false;      // IDIST_VISITED=onchip: the on-chip set whatever the policy says (test / A-B knob)
+    bool combine = true;          // IDIST_COMBINE=0: every scalar host-pointer call makes its own launch, however many are in flight
     bool sync_flag = true;        // IDIST_SYNC=stream: narrow host-pointer calls wait with hipStreamSynchronize instead of for the completion
                                   // word the kernel writes to the context's pinned buffer (A/B knob)
     bool tie_spill_first = false; // IDIST_TIE_SPILL=1: strict ties go to the HBM bags at the first overflow instead of growing the LDS region first (test knob)
@@ -204,6 +222,7 @@ struct Knobs {
         if (const char* e = getenv("IDIST_KERNEL_EVENTS")) k.events = e[0] != '0';
         if (const char* e = getenv("IDIST_TIE_SPILL")) k.tie_spill_first = e[0] == '1';
         if (const char* e = getenv("IDIST_SYNC")) k.sync_flag = e[0] != 's';
+        if (const char* e = getenv("IDIST_COMBINE")) k.combine = e[0] != '0';
         if (const char* e = getenv("IDIST_TAB_LOG2")) k.tab_log2 = std::min(13u, std::max(5u, (uint32_t)atoi(e)));
         return k;
     }
@@ -1332,6 +1351,34 @@ idist_status idist_search_ctx_kernel_times(idist_search_ctx* ctx, float* ms, uin
     return IDIST_OK;
 }
 
+static idist_status search_batch_impl(const idist_index* idx, idist_search_ctx* ctx, const float* queries, uint32_t nq,
+                                      uint32_t* out_pid, float* out_dist, uint32_t* out_count, uint32_t* out_counters);
+
+// A leader's launch for the scalar calls it took along (idist_combine.hpp): on the leader's own context, one query each
+static void run_combined(const idist_index* idx, idist_search_ctx* ctx, std::vector<ScalarReq*>& b) {
+    const uint32_t k = (uint32_t)b.size(), ef = idx->cfg.ef_search, dim = idx->dim;
+    idist_status st;
+    if (k == 1) {
+        st = search_batch_impl(idx, ctx, b[0]->q, 1, b[0]->pid, b[0]->dist, b[0]->cnt, b[0]->ctr);
+    } else {
+        std::vector<float> q((size_t)k * dim), dd((size_t)k * ef);
+        std::vector<uint32_t> pid((size_t)k * ef), cnt(k), ctr((size_t)k * 3);
+        for (uint32_t i = 0; i < k; i++) memcpy(q.data() + (size_t)i * dim, b[i]->q, (size_t)dim * 4);
+        st = search_batch_impl(idx, ctx, q.data(), k, pid.data(), dd.data(), cnt.data(), ctr.data());
+        if (st == IDIST_OK)
+            for (uint32_t i = 0; i < k; i++) {
+                memcpy(b[i]->pid, pid.data() + (size_t)i * ef, (size_t)ef * 4);
+                memcpy(b[i]->dist, dd.data() + (size_t)i * ef, (size_t)ef * 4);
+                b[i]->cnt[0] = cnt[i];
+                if (b[i]->ctr) memcpy(b[i]->ctr, ctr.data() + (size_t)i * 3, 12);
+            }
+    }
+    for (ScalarReq* r : b) {
+        r->st = st;
+        if (st != IDIST_OK) r->err = g_err;
+    }
+}
+
 idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, const float* queries, uint32_t nq,
                                 uint32_t* out_pid, float* out_dist, uint32_t* out_count, uint32_t* out_counters) {
     CHK(check_ctx(idx, ctx));
@@ -1344,6 +1391,20 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
         return IDIST_OK;
     }
     if (!out_pid || !out_dist) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
+    // The reference's scalar call, possibly from many threads at once (one Search each, core/lib.rs:352-356): beyond eight
+    // launches in flight on this index a call rides along in another thread's launch instead of making its own
+    if (nq == 1 && ctx->knobs.combine) {
+        ScalarReq r{queries, out_pid, out_dist, out_count, out_counters};
+        idx->comb.submit(r, [&](std::vector<ScalarReq*>& b) { run_combined(idx, ctx, b); });
+        if (r.st != IDIST_OK) g_err = r.err;
+        return r.st;
+    }
+    return search_batch_impl(idx, ctx, queries, nq, out_pid, out_dist, out_count, out_counters);
+}
+
+static idist_status search_batch_impl(const idist_index* idx, idist_search_ctx* ctx, const float* queries, uint32_t nq,
+                                      uint32_t* out_pid, float* out_dist, uint32_t* out_count, uint32_t* out_counters) {
+    const uint32_t ef = idx->cfg.ef_search;
     HIPCHK(hipSetDevice(idx->device));
     const size_t qb = (size_t)nq * idx->dim * 4, ob = (size_t)nq * ef * 4;
     // Narrow batches — the reference's call is ONE query per Hnsw::search: query and results cross PCIe through one

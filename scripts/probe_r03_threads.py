@@ -25,14 +25,14 @@ if os.environ.get("PB_CHILD"):
     torch.cuda.synchronize()
     h = ida.Hnsw.from_device_points(d_pts.data_ptr(), n, dim, ida.Builder())
     row = {"variant": os.environ["PB_CHILD"]}
-    for T in (1, 2, 4, 8, 16, 32):
+    for T in (1, 2, 4, 8, 16, 32, 64):
         row[f"T{T}"] = round(bench.scalar_calls(h, ida, q, T, max(100, 2400 // T)), 1)
         row[f"T{T}_kernel_ms"] = round(bench.scalar_calls.kernel_ms, 4)
     print("ROW " + json.dumps(row), flush=True)
     sys.exit(0)
 
 fo = open(sys.argv[1], "a")
-VARIANTS = [("default", {}), ("sync_stream", {"IDIST_SYNC": "stream"}), ("hwq4", {"GPU_MAX_HW_QUEUES": "4"}), ("hwq8", {"GPU_MAX_HW_QUEUES": "8"}), ("hwq16", {"GPU_MAX_HW_QUEUES": "16"}),
+VARIANTS = [("default", {}), ("no_combine", {"IDIST_COMBINE": "0"}), ("sync_stream", {"IDIST_SYNC": "stream"}), ("hwq4", {"GPU_MAX_HW_QUEUES": "4"}), ("hwq8", {"GPU_MAX_HW_QUEUES": "8"}), ("hwq16", {"GPU_MAX_HW_QUEUES": "16"}),
             ("no_events", {"IDIST_KERNEL_EVENTS": "0"}), ("no_events_hwq16", {"IDIST_KERNEL_EVENTS": "0", "GPU_MAX_HW_QUEUES": "16"}),
             ("no_events_hwq32_staged", {"IDIST_KERNEL_EVENTS": "0", "GPU_MAX_HW_QUEUES": "32", "IDIST_NO_ZERO_COPY": "1"})]
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else None

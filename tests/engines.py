@@ -21,7 +21,7 @@ def engine_params():
 
 def build_emu():
     srcs = [os.path.join(ROOT, "instant-distance_amd", "csrc", f) for f in
-            ("idist_capi.hip", "idist_kernels.hpp", "idist_device.hpp")]
+            ("idist_capi.hip", "idist_kernels.hpp", "idist_device.hpp", "idist_mfma.hpp", "idist_combine.hpp")]
     srcs += [os.path.join(ROOT, "tests", "simt", f) for f in ("hip_emu.hpp", "hip_emu.cpp")]
     def stale():
         return not os.path.exists(EMU_SO) or os.path.getmtime(EMU_SO) < max(os.path.getmtime(s) for s in srcs)

@@ -151,3 +151,50 @@ def test_narrow_host_batches_zero_copy_equals_staged(eng, oracle, monkeypatch):
                 assert np.array_equal(got.counters, want.counters[lo:lo + width])
         for k in env:
             monkeypatch.delenv(k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("combine", ["1", "0"])
+def test_scalar_calls_from_many_threads_gpu(engine_loader, oracle, monkeypatch, combine):
+    """The reference's concurrency model (core/lib.rs:352-356): many threads, one `Search` each, scalar `Hnsw::search`
+    calls on ONE shared index.  Beyond eight launches in flight a call rides along in another thread's launch
+    (idist_combine.hpp); every caller must still get exactly its own query's answer — ids, order, counts, distance bits,
+    work counters — and so it must with every call launching by itself (IDIST_COMBINE=0)."""
+    import threading
+
+    monkeypatch.setenv("IDIST_COMBINE", combine)
+    ida = engine_loader("gpu")
+    pts, oix, _ = pc.oracle_graph(oracle, 20000, 96, "uniform", 0, 61, 1, 100)
+    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder())
+    rng = np.random.default_rng(62)
+    n_thr, calls = 24, 40
+    q = pc.gen_points(rng, n_thr * calls, pts.shape[1])
+    want = oix.search(q, threads=8)
+    errs = []
+    gate = threading.Barrier(n_thr)
+
+    def work(t):
+        try:
+            s = ida.Search()
+            h.search_batch(q[:1], s)                        # the context's buffers come into being
+            gate.wait()
+            for i in range(calls):
+                j = t * calls + i
+                got = h.search_batch(q[j:j + 1], s, counters=True)
+                assert np.array_equal(got.pid[0], want.pid[j]) and got.count[0] == want.count[j], (t, i)
+                assert np.array_equal(pc.bits(got.distance[0]), pc.bits(want.dist[j])), (t, i)
+                assert np.array_equal(got.counters[0], want.counters[j]), (t, i)
+        except BaseException as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+            try:
+                gate.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(n_thr)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "a scalar call never returned"
+    assert not errs, errs[:3]
