@@ -39,8 +39,8 @@ BUILD_VARIANTS = (("on-chip", {}),
                   ("on-chip classic", {"IDIST_WALK": "classic"}),
                   ("on-chip, full ids (frozen at 7/8, distance log in the id form)", {"IDIST_TAB_FORMAT": "ids"}),
                   ("on-chip, full ids, small set then bitmap", {"IDIST_TAB_FORMAT": "ids", "IDIST_TAB_LOG2": "7"}),
-                  ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7"}),
-                  ("on-chip, set of 32 ids: bitmap from the start", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}))
+                  ("on-chip, smallest set the build allows (IDIST_TAB_LOG2 is clamped to 8: 512 quotients) then bitmap", {"IDIST_TAB_LOG2": "7"}),
+                  ("on-chip classic, smallest set then bitmap", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}))
 
 
 @contextlib.contextmanager

@@ -133,7 +133,7 @@ def test_build_exact_extend_candidates(eng, oracle, n, dim, kw):
     for byte.  The schedule is sequential whatever max_batch says."""
     ida, kind = eng
     scale = 1 if kind != "gpu" else 6
-    both = (("on-chip", {}), ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7"}))
+    both = (("on-chip", {}), ("on-chip, smallest set the build allows (clamped to 256 ids) then bitmap", {"IDIST_TAB_LOG2": "7"}))
     pc.check_build_exact(ida, oracle, n=n * scale, dim=dim, seed=n, extend=True, max_batch=0, variants=both, **kw)
 
 
