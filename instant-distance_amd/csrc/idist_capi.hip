@@ -454,7 +454,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     uint64_t* d_tie_spill = nullptr;
     uint32_t* d_nbr_dist = nullptr;
     uint32_t *d_edge_pid = nullptr, *d_edge_dist = nullptr, *d_head = nullptr, *d_next = nullptr, *d_touched = nullptr;
-    uint32_t* d_small = nullptr;           // [0] n_touched, [1..6] queue (A, B, n_slow, B2, A2, A3), [8] status
+    uint32_t* d_small = nullptr;           // [0] n_touched, [1..5] queue (A, B, n_slow, B2, A2), [8] status
     uint64_t *d_wbuf = nullptr, *d_dlog_log = nullptr;
     uint32_t* d_dlog_pd = nullptr;
     uint32_t* d_wcount = nullptr;

@@ -14,9 +14,13 @@
 //                           live candidates are exactly the un-expanded entries
 //                           of that array (DESIGN.md §3 proves the equivalence;
 //                           `push` works on it in registers, w_push_merge).
+//                           Live distance ties that do not fit behind it go to a
+//                           bag in HBM (WState::spill): unbounded like that heap.
 //   * visited             : exact set membership (core/types.rs:13-59): a
-//                           two-bucket hash set of ids in LDS per walk; what it
-//                           cannot hold goes to one bit per point and slot in HBM.
+//                           two-bucket hash set in LDS per walk — full ids, or
+//                           16-bit quotients of two bijective hashes (q16_*: twice
+//                           the ids in the same LDS); what it cannot hold goes to
+//                           one bit per point and slot in HBM.
 #pragma once
 #ifdef IDIST_EMU
 #include "hip_emu.hpp"   // tests/simt: CPU lockstep emulation of one wave (test infrastructure)

@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KERNELS = ("build_select_mfma_kernel", "mfma_dist_kernel", "build_insert_kernel", "build_update_fast_kernel", "build_edge_dist_kernel",
+KERNELS = ("build_select_mfma_kernel", "mfma_dist_kernel", "build_insert_kernel", "build_update_fast_kernel",
            "build_update_kernel", "copy_rows_kernel", "rerank_kernel")
 CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md: max clock; effective clock = GRBM_GUI_ACTIVE / kernel time where collected
 N_SIMD = 256 * 4

@@ -11,7 +11,7 @@ out = sys.argv[1]
 dest = sys.argv[2] if len(sys.argv) > 2 else None
 what = sys.argv[3] if len(sys.argv) > 3 else "`python bench.py` (C3: 1M x 300-d, 10k queries, ef_search=100)"
 res = {}
-KEYS = ("search_kernel", "build_insert_kernel", "build_select_mfma_kernel", "build_edge_dist_kernel", "copy_rows_kernel", "build_select_kernel", "build_update_fast_kernel", "build_update_simple_kernel", "build_update_kernel",
+KEYS = ("search_kernel", "build_insert_kernel", "build_select_mfma_kernel", "copy_rows_kernel", "build_select_kernel", "build_update_fast_kernel", "build_update_simple_kernel", "build_update_kernel",
         "bruteforce_kernel", "distance_batch_kernel", "mfma_dist_kernel", "rerank_kernel", "kth_threshold_kernel",
         "row_norms_kernel", "permute_rows_kernel", "snapshot_kernel", "validate_rows_kernel")
 
