@@ -18,14 +18,14 @@ INVALID = 0xFFFFFFFF
 SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by index size and ef_search)", {}),
                    ("on-chip, quotient set", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "q16"}),
                    ("four waves per query, quotient set", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_FORMAT": "q16"}),
-                   ("four waves per query, set of 128 ids then bitmap", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_LOG2": "7"}),
+                   ("four waves per query, 512-B quotient set (256 ids) then bitmap", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_LOG2": "7"}),
                    ("on-chip classic", {"IDIST_WALK": "classic", "IDIST_VISITED": "onchip"}),
                    ("on-chip, full ids", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "ids"}),
                    ("four waves per query, full ids, set of 128 ids then bitmap",
                     {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_LOG2": "7", "IDIST_TAB_FORMAT": "ids"}),
                    ("on-chip classic, full ids, set of 32 ids", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic", "IDIST_TAB_FORMAT": "ids"}),
-                   ("on-chip, set of 128 ids then bitmap", {"IDIST_TAB_LOG2": "7", "IDIST_QUAD_NQ": "0"}),
-                   ("on-chip, set of 32 ids: bitmap from the start", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}),
+                   ("on-chip, 512-B quotient set (256 ids) then bitmap", {"IDIST_TAB_LOG2": "7", "IDIST_QUAD_NQ": "0"}),
+                   ("on-chip classic, 128-B quotient set (64 ids): bitmap almost from the start", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}),
                    ("bitmap overlap", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "0"}),
                    ("bitmap latency", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "4000000000"}),
                    ("bitmap classic", {"IDIST_VISITED": "bitmap", "IDIST_LATENCY_NQ": "0", "IDIST_WALK": "classic"}))
