@@ -34,6 +34,7 @@
  *   IDIST_COMBINE=0         every scalar host-pointer call makes its own launch (no riding along in another thread's launch)
  *   IDIST_SYNC=stream       narrow host-pointer calls wait with hipStreamSynchronize instead of for the kernel's completion word
  *   IDIST_TIE_SPILL=1       strict ties take the HBM bags at the first overflow instead of growing the LDS region first
+ *   IDIST_BUILD_QUAD=0      narrow build steps (<= two insertions per CU) with one wave per insertion instead of four
  *   IDIST_BUILD_A_REGS=512  descents with one 512-register wave per SIMD instead of 256-register waves
  *   IDIST_QUAD_NQ=<n>       batches of <= n queries run four waves per query (default two queries per CU; 0 = never)
  *   IDIST_LATENCY_NQ=<n>    bitmap walk only: batches of <= n queries run its latency variant (default 1024)

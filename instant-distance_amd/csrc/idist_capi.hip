@@ -477,6 +477,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // waves find room on every SIMD) or 512 (IDIST_BUILD_A_REGS=512, more rounds in flight per wave).  C3: 1.26 vs 1.29-1.32 s
     bool a_regs256 = tab16;
     if (const char* e = getenv("IDIST_BUILD_A_REGS")) a_regs256 = tab16 && atoi(e) == 256;
+    // steps of at most two insertions per CU run four waves per insertion (IDIST_BUILD_QUAD=0: never)
+    const bool a_quad = !(getenv("IDIST_BUILD_QUAD") && getenv("IDIST_BUILD_QUAD")[0] == '0');
+    const uint32_t quad_B = (uint32_t)ix->n_cu * 2u;
     // what one CU's LDS holds of them (the sequential schedule runs nothing beside the descents)
     const uint32_t a_waves_max = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)((160u * 1024u) / smem)));
     a_waves = std::min(a_waves, a_waves_max);
@@ -651,6 +654,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         auto kA16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true, false, true)>; \
         auto kAo16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
         /* two descent waves per SIMD: 256 registers each, fewer rounds in flight per wave, more waves */ \
+        /* narrow steps (the growth phase of a layer, max_batch = 1): four waves per insertion, like narrow search batches */ \
+        auto kAq16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, true, true)>; \
         auto kAo16w2 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
         auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
@@ -660,6 +665,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         auto kA2m = build_select_mfma_kernel<NB_, RS_, TAIL_>;                                     \
         if (ext) { IDIST_LAUNCH(kX, 1, 64, smemX, sA, viewA, aA, d_ext_work, ext_cap); }           \
         else if (classic && tab16) { IDIST_LAUNCH(kA16, gridA, 64, smem, sA, viewA, aA); }         \
+        else if (tab16 && a_quad && B <= quad_B) { IDIST_LAUNCH(kAq16, std::min(B, slots), 256, smem, sA, viewA, aA); } \
         else if (tab16 && a_regs256) { IDIST_LAUNCH(kAo16w2, gridA, 64, smem, sA, viewA, aA); }    \
         else if (tab16) { IDIST_LAUNCH(kAo16, gridA, 64, smem, sA, viewA, aA); }                   \
         else if (classic) { IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA); }                    \

@@ -474,7 +474,7 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
         st.ef = cur <= (int)a.layer ? (int)a.efc : 1;             // :448-452
         if (cur > (int)a.layer) {                                 // :453-457
             const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dl);
+            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dl, walk_quad(LAT) ? sm.ctl : nullptr);
             w_cull(st);
             visited_clear(vis);
             visited_begin(vis, (uint32_t)st.plen);
@@ -489,19 +489,28 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
                     dlog_append(dl, on ? vis_index(vis, (uint32_t)k) : -1, (uint32_t)(k >> 32));
                 }
         } else {                                                  // :458-461
-            search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dl);
+            search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dl, walk_quad(LAT) ? sm.ctl : nullptr);
             break;
         }
     }
 }
 
+// Walk codes with the quad bit (narrow steps: the growth phase of a layer, max_batch = 1) run four-wave workgroups like the
+// search kernel: wave 0 is the descent below, waves 1-3 take their share of every distance pass.
 template <int NB, int RS, int TAIL, int LAT = 0>
-__global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(IndexView ix, BuildArgs a) {
+__global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(IndexView ix, BuildArgs a) {
     IDIST_DYN_SMEM(smem_raw);
     const Smem sm = carve(smem_raw, ix.stride, a.wcap, true, a.vis.dirty_words);
     uint64_t* sel = sm.aux + 64 + 8;
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
+    if constexpr (walk_quad(LAT)) {
+        const int wv = (int)uniform_u32(threadIdx.x >> 6);
+        if (wv != 0) {
+            quad_helper_loop<NB, RS, TAIL>(ix, sm.q, sm.ctl, sm.act_pid, sm.act_dist, wv);
+            return;
+        }
+    }
     Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words, nullptr, 0};
     visited_attach_tab(vis, sm.bloom, a.tab_log2);                    // the descent always keeps its visited set on chip
     if constexpr (walk_vis16(LAT)) visited_attach_q16(vis, a.tab_log2, a.ubits);
@@ -541,6 +550,7 @@ __global__ __launch_bounds__(64) IDIST_WAVES_ATTR(LAT) void build_insert_kernel(
         status |= st.status;
         visited_clear(vis);                                           // leave the slot empty for its next descent
     }
+    if constexpr (walk_quad(LAT)) quad_release_helpers(sm.ctl);
     if (lane == 0) {
         if (status) atomicOr(a.status, status);
         if (tot.n_dist | tot.n_exp0 | tot.n_expU) {

@@ -32,6 +32,9 @@ CASES = {
     "onestream": {"IDIST_BUILD_PIPELINE": "0"},
     "onestream_r256": {"IDIST_BUILD_PIPELINE": "0", "IDIST_BUILD_A_REGS": "256"},
     "a2tile": {"IDIST_BUILD_A2": "tile"},
+    "noquad": {"IDIST_BUILD_QUAD": "0"},
+    "seq20k": {"PB_MAX_BATCH": "1", "PB_N_SEQ": "20000"},
+    "seq20k_noquad": {"PB_MAX_BATCH": "1", "PB_N_SEQ": "20000", "IDIST_BUILD_QUAD": "0"},
     "chunk4": {"IDIST_BUILD_CHUNK": "4"},
     "default2": {},
 }
@@ -41,14 +44,15 @@ for nm in names:
     env = CASES[nm]
     os.environ.update(env)
     try:
-        h = ida.Hnsw.from_device_points(d_pts.data_ptr(), n, dim, ida.Builder())
+        nn = int(env.get("PB_N_SEQ", n))                       # sequential (max_batch = 1) cases build a prefix
+        h = ida.Hnsw.from_device_points(d_pts.data_ptr(), nn, dim, ida.Builder().max_batch(int(env.get("PB_MAX_BATCH", 0))))
         st = h.build_stats()
         if truth is None:
             truth, _ = h.bruteforce(q, 10)
         got = h.search_batch(q, ida.Search())
         rec = float(np.mean([len(set(got.pid[i, :10].tolist()) & set(truth[i].tolist())) / 10 for i in range(len(q))]))
         zero, _ = h.into_parts()
-        row = dict(case=nm, n=n, dim=dim, env=env, seconds=round(st.seconds, 4), points_per_s=round(n / st.seconds), recall_at_10=round(rec, 4),
+        row = dict(case=nm, n=nn, dim=dim, env=env, seconds=round(st.seconds, 4), points_per_s=round(nn / st.seconds), recall_at_10=round(rec, 4),
                    n_dist=int(st.n_dist), n_sel_pairs=int(st.n_sel_pairs), n_heur_rows=int(st.n_heur_rows), n_updates=int(st.n_updates),
                    n_updates_full=int(st.n_updates_full), batches=int(st.n_batches), graph_checksum=int(zero.astype(np.uint64).sum()))
         del h, zero

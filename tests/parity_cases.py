@@ -33,7 +33,9 @@ SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by
 # of the on-chip visited set — it never runs four waves per item and has no bitmap-only variant.
 # (the third field: the variant runs every selection in the reference's own order, so its count of distance calls inside
 #  select_heuristic / add_neighbor_heuristic must equal the oracle's n_heur)
-BUILD_VARIANTS = (("on-chip", {}),
+BUILD_VARIANTS = (("on-chip (narrow steps: four waves per insertion)", {}),
+                  ("on-chip, one wave per insertion also in narrow steps", {"IDIST_BUILD_QUAD": "0"}),
+                  ("on-chip, 512-register descent waves", {"IDIST_BUILD_QUAD": "0", "IDIST_BUILD_A_REGS": "512"}),
                   ("reference-order kernels: LDS-tile selection, every update from scratch", {"IDIST_BUILD_A2": "tile", "IDIST_BUILD_NO_FAST": "1"}),
                   ("step A2 with the LDS-tile kernel instead of the Gram matrix on MFMA", {"IDIST_BUILD_A2": "tile"}),
                   ("on-chip classic", {"IDIST_WALK": "classic"}),
@@ -48,7 +50,7 @@ def search_variant(env):
     if isinstance(env, str):                     # a bare IDIST_LATENCY_NQ value
         env = {"IDIST_LATENCY_NQ": env}
     keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ", "IDIST_BUILD_A2",
-            "IDIST_TAB_FORMAT", "IDIST_BUILD_NO_FAST")
+            "IDIST_TAB_FORMAT", "IDIST_BUILD_NO_FAST", "IDIST_BUILD_QUAD", "IDIST_BUILD_A_REGS")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)
