@@ -45,6 +45,29 @@ BUILD_VARIANTS = (("on-chip (narrow steps: four waves per insertion)", {}),
                   ("on-chip classic, smallest set then bitmap", {"IDIST_TAB_LOG2": "5", "IDIST_WALK": "classic"}))
 
 
+def _emulated():
+    """True when the engine under test is the CPU lockstep emulator (tests/simt): a build there costs seconds per variant."""
+    from instant_distance_amd import _capi
+    return _capi.lib().path.endswith("libidist_emu.so")
+
+
+def pick_variants(variants, seed, keep):
+    """GPU: every variant for every case.  Emulator: the default plus `keep` others, rotating with the case's seed, so that
+    the CPU suite stays within minutes while every variant is still run by several cases."""
+    vs = list(variants)
+    if not _emulated() or len(vs) <= keep + 1:
+        return vs
+    rest = vs[1:]
+    picked = []
+    for i in range(len(rest)):
+        v = rest[(seed * 5 + i * 7) % len(rest)]           # 7 is coprime to both list lengths
+        if v not in picked:
+            picked.append(v)
+        if len(picked) == keep:
+            break
+    return [vs[0]] + picked
+
+
 @contextlib.contextmanager
 def search_variant(env):
     if isinstance(env, str):                     # a bare IDIST_LATENCY_NQ value
@@ -133,7 +156,7 @@ def check_search_parity(ida, oracle, n, dim, ef_search=100, metric=0, kind="unif
     if kind == "uniform" and nq > 2:
         q[1] = pts[min(5, n - 1)]          # a stored point: distance 0 first (test.py:15-35)
     want = oix.search(q, threads=1)
-    for _, lat in SEARCH_VARIANTS:
+    for _, lat in pick_variants(SEARCH_VARIANTS, seed, 7):
         with search_variant(lat):
             got = h.search_batch(q, ida.Search(), counters=True)
         check_search_result(got, want)
@@ -158,7 +181,7 @@ def check_build_exact(ida, oracle, n, dim, metric=0, kind="uniform", ef_construc
     oix = oracle.Index.build(pts, cfg, threads=1)
     b = (ida.Builder().metric(metric).max_batch(max_batch).ef_construction(ef_construction)
          .select_heuristic(ida.Heuristic(extend, keep_pruned) if heuristic else None))
-    for _, lat in (variants or BUILD_VARIANTS):   # the descent of an insertion has the same variants as the search
+    for _, lat in (variants or pick_variants(BUILD_VARIANTS, seed, 4)):   # the descent of an insertion has the same variants as the search
         with search_variant(lat):
             h = ida.Hnsw.from_ordered_points(pts, b)
         zero, layers = h.into_parts()

@@ -221,7 +221,7 @@ def test_build_batched_is_schedule_independent(eng, oracle, monkeypatch):
     give byte-identical graphs."""
     ida, kind = eng
     rng = np.random.default_rng(4)
-    pts = pc.gen_points(rng, S(kind, 300, 60000), S(kind, 6, 48), "lowrank" if kind == "gpu" else "uniform")
+    pts = pc.gen_points(rng, S(kind, 150, 60000), S(kind, 6, 48), "lowrank" if kind == "gpu" else "uniform")
     b = ida.Builder().max_batch(S(kind, 16, 0))
     ref = None
     envs = [{}, {"IDIST_BUILD_CHUNK": "5"}, {"IDIST_BUILD_NO_FAST": "1"}, {"IDIST_LATENCY_NQ": "0"}, {"IDIST_BUILD_QUAD": "0"},
