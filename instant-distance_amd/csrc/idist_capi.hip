@@ -145,12 +145,16 @@ struct ScalarReq {
     idist_status st = IDIST_OK;
     std::string err;
     bool done = false, lead = false;
+    int slot = -1;
     std::condition_variable cv;
 };
 
 struct idist_index {
     uint64_t uid = 0;            // never reused: a context is bound to (pointer, uid), not to the pointer alone
     mutable idist::Combiner<ScalarReq> comb;   // scalar calls of many threads -> few launches (the index is shared, `&self`)
+    // one context per leader slot for the batches a leader takes along: sized by the batches (a caller's own `Search` may be
+    // backed for one query only), created on a slot's first combined launch, at most comb.max_leaders() of them
+    mutable idist_search_ctx* comb_ctx[16] = {nullptr};
     int32_t device = 0;
     idist_config cfg{};
     uint32_t n = 0, dim = 0;
@@ -245,6 +249,7 @@ struct idist_search_ctx {
     size_t io_cap = 0;             // bytes of that buffer: 64 KB on first use, grown on demand up to kIoMaxBytes
     uint32_t done_seq = 0;         // completion word of the last narrow host-pointer launch (h_io + kIoStatusSlots * 4)
     double call_ns_ema = 0.0;      // how long such a call has taken lately: the host sleeps through the first half of it
+    uint64_t n_flag_calls = 0;
     static constexpr size_t kIoMinBytes = 64 * 1024, kIoMaxBytes = 256 * 1024, kIoStatusSlots = 256, kIoHeadBytes = kIoStatusSlots * 4 + 64;   // ~100 queries: beyond that the staged copies are as fast (profiles/probe_r02_quad_single_query_phases.jsonl)
     hipStream_t stream = nullptr;
     hipEvent_t ev0[IDIST_EVENT_RING] = {nullptr}, ev1[IDIST_EVENT_RING] = {nullptr};
@@ -1217,6 +1222,7 @@ idist_status idist_index_set_ef_search(idist_index* idx, uint32_t ef_search) {
 void idist_index_free(idist_index* idx) {
     if (!idx) return;
     hipSetDevice(idx->device);
+    for (idist_search_ctx* c : idx->comb_ctx) idist_search_ctx_free(c);
     hipFree(idx->d_points);
     hipFree(idx->d_zero);
     hipFree(idx->d_upper);
@@ -1360,13 +1366,17 @@ idist_status idist_search_ctx_kernel_times(idist_search_ctx* ctx, float* ms, uin
 static idist_status search_batch_impl(const idist_index* idx, idist_search_ctx* ctx, const float* queries, uint32_t nq,
                                       uint32_t* out_pid, float* out_dist, uint32_t* out_count, uint32_t* out_counters);
 
-// A leader's launch for the scalar calls it took along (idist_combine.hpp): on the leader's own context, one query each
-static void run_combined(const idist_index* idx, idist_search_ctx* ctx, std::vector<ScalarReq*>& b) {
+// A leader's launch for the scalar calls it took along (idist_combine.hpp).  Alone: on the leader's own context.  With
+// company: on its slot's context, which grows with the batches (the leader's own may be a one-slot `Search`).
+static void run_combined(const idist_index* idx, idist_search_ctx* ctx, std::vector<ScalarReq*>& b, int slot) {
     const uint32_t k = (uint32_t)b.size(), ef = idx->cfg.ef_search, dim = idx->dim;
-    idist_status st;
+    idist_status st = IDIST_OK;
     if (k == 1) {
         st = search_batch_impl(idx, ctx, b[0]->q, 1, b[0]->pid, b[0]->dist, b[0]->cnt, b[0]->ctr);
+    } else if (!idx->comb_ctx[slot] && (st = idist_search_ctx_new(idx, 0, &idx->comb_ctx[slot])) != IDIST_OK) {
+        // (reported to every caller of the batch below)
     } else {
+        ctx = idx->comb_ctx[slot];
         std::vector<float> q((size_t)k * dim), dd((size_t)k * ef);
         std::vector<uint32_t> pid((size_t)k * ef), cnt(k), ctr((size_t)k * 3);
         for (uint32_t i = 0; i < k; i++) memcpy(q.data() + (size_t)i * dim, b[i]->q, (size_t)dim * 4);
@@ -1401,7 +1411,7 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
     // launches in flight on this index a call rides along in another thread's launch instead of making its own
     if (nq == 1 && ctx->knobs.combine) {
         ScalarReq r{queries, out_pid, out_dist, out_count, out_counters};
-        idx->comb.submit(r, [&](std::vector<ScalarReq*>& b) { run_combined(idx, ctx, b); });
+        idx->comb.submit(r, [&](std::vector<ScalarReq*>& b, int slot) { run_combined(idx, ctx, b, slot); });
         if (r.st != IDIST_OK) g_err = r.err;
         return r.st;
     }
@@ -1454,9 +1464,11 @@ static idist_status search_batch_impl(const idist_index* idx, idist_search_ctx* 
                 // The kernel's last workgroup writes `seq` into the pinned buffer behind its results.  One Search per thread
                 // is the reference's model, so waiting must not burn a core per thread: sleep through the first half of what
                 // such a call has been taking, then poll the word; a stream synchronisation only if it stays away for 2 s.
+                bool overslept = false;
                 if (ctx->call_ns_ema > 200e3) {
                     struct timespec ts = {0, (long)(ctx->call_ns_ema * 0.5)};
                     nanosleep(&ts, nullptr);
+                    overslept = *h_done == seq;                       // done before we looked: the estimate is too long
                 }
                 bool seen = false;
                 for (uint64_t spins = 0; !(seen = (*h_done == seq)); spins++) {
@@ -1467,7 +1479,9 @@ static idist_status search_batch_impl(const idist_index* idx, idist_search_ctx* 
                 std::atomic_thread_fence(std::memory_order_acquire);
                 if (!seen) HIPCHK(hipStreamSynchronize(ctx->stream));
                 const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
-                ctx->call_ns_ema = ctx->call_ns_ema == 0.0 ? ns : 0.8 * ctx->call_ns_ema + 0.2 * ns;
+                if (overslept) ctx->call_ns_ema *= 0.7;
+                else if (ctx->n_flag_calls++ > 0)                     // (the first call also allocated: not a sample)
+                    ctx->call_ns_ema = ctx->call_ns_ema == 0.0 ? ns : 0.8 * ctx->call_ns_ema + 0.2 * ns;
             } else {
                 HIPCHK(hipStreamSynchronize(ctx->stream));
             }

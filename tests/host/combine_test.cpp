@@ -12,7 +12,7 @@
 #include "../../instant-distance_amd/csrc/idist_combine.hpp"
 
 struct Req {
-    int q = 0, out = -1, served = 0;
+    int q = 0, out = -1, served = 0, slot = -1;
     bool done = false, lead = false;
     std::condition_variable cv;
 };
@@ -24,12 +24,15 @@ int main(int argc, char** argv) {
     idist::Combiner<Req> comb(max_leaders, max_batch);
     std::atomic<int> in_flight{0}, max_in_flight{0}, launches{0}, bad{0};
     std::atomic<long> served{0}, widest{0};
+    std::vector<std::atomic<int>> slot_busy(max_leaders);
+    for (auto& x : slot_busy) x = 0;
     auto worker = [&](int t) {
         for (int i = 0; i < calls; i++) {
             Req r;
             r.q = t * 100000 + i;
-            comb.submit(r, [&](std::vector<Req*>& b) {
+            comb.submit(r, [&](std::vector<Req*>& b, int slot) {
                 if (b[0] != &r) bad++;                                    // a leader's own request leads its batch
+                if (slot < 0 || slot >= (int)max_leaders || slot_busy[slot].exchange(1)) bad++;   // a slot serves one leader at a time
                 if (b.size() > max_batch) bad++;
                 const int now = ++in_flight;
                 int m = max_in_flight.load();
@@ -40,6 +43,7 @@ int main(int argc, char** argv) {
                 std::this_thread::sleep_for(std::chrono::microseconds(200 + (r.q % 7) * 20));
                 for (Req* x : b) { x->out = x->q * 2 + 1; x->served++; }
                 served += (long)b.size();
+                slot_busy[slot] = 0;
                 --in_flight;
             });
             if (!r.done || r.served != 1 || r.out != r.q * 2 + 1) bad++;

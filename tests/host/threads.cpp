@@ -2,6 +2,7 @@
 // index, each owns a context (`&mut Search`, core/lib.rs:352-356) and issues scalar idist_search_batch(nq = 1) calls.
 // Every call must return exactly what one wide batch call returns for that query (ids, distance bits, count); prints the
 // aggregate calls/s.  usage: threads <n> <dim> <threads> <calls_per_thread>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -41,14 +42,19 @@ int main(int argc, char** argv) {
     }
     std::vector<int> bad(T, 0);
     std::vector<std::thread> ts;
-    const auto t0 = std::chrono::steady_clock::now();
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
     for (int t = 0; t < T; t++)
         ts.emplace_back([&, t] {
             idist_search_ctx* c = nullptr;
-            if (idist_search_ctx_new(idx, 1, &c) != IDIST_OK) { bad[t] = 1 << 20; return; }
+            if (idist_search_ctx_new(idx, 1, &c) != IDIST_OK) { bad[t] = 1 << 20; ready++; return; }
             std::vector<uint32_t> pid(ef);
             std::vector<float> dist(ef);
             uint32_t cnt = 0;
+            // Search::default() and the first call (the context's buffers come into being) are not what is timed
+            if (idist_search_batch(idx, c, q.data(), 1, pid.data(), dist.data(), &cnt, nullptr) != IDIST_OK) bad[t]++;
+            ready++;
+            while (!go.load()) std::this_thread::yield();
             for (int i = 0; i < calls; i++) {
                 const size_t j = (size_t)t * calls + i;
                 if (idist_search_batch(idx, c, q.data() + j * dim, 1, pid.data(), dist.data(), &cnt, nullptr) != IDIST_OK) { bad[t]++; continue; }
@@ -58,6 +64,9 @@ int main(int argc, char** argv) {
             }
             idist_search_ctx_free(c);
         });
+    while (ready.load() < T) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go = true;
     for (auto& th : ts) th.join();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     int nbad = 0;
