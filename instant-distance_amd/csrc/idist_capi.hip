@@ -135,6 +135,8 @@ idist_status validate_config(const idist_config* cfg, bool for_build) {
 
 }  // namespace
 
+constexpr uint32_t kCombineLeaders = 8, kCombineBatch = 64;   // launches in flight per index before calls ride along; widest combined launch
+
 // one scalar Hnsw::search call waiting to be served, alone or as part of another thread's launch (idist_combine.hpp)
 struct ScalarReq {
     const float* q;
@@ -151,10 +153,10 @@ struct ScalarReq {
 
 struct idist_index {
     uint64_t uid = 0;            // never reused: a context is bound to (pointer, uid), not to the pointer alone
-    mutable idist::Combiner<ScalarReq> comb;   // scalar calls of many threads -> few launches (the index is shared, `&self`)
+    mutable idist::Combiner<ScalarReq> comb{kCombineLeaders, kCombineBatch};   // scalar calls of many threads -> few launches (the index is shared, `&self`)
     // one context per leader slot for the batches a leader takes along: sized by the batches (a caller's own `Search` may be
     // backed for one query only), created on a slot's first combined launch, at most comb.max_leaders() of them
-    mutable idist_search_ctx* comb_ctx[16] = {nullptr};
+    mutable idist_search_ctx* comb_ctx[kCombineLeaders] = {nullptr};
     int32_t device = 0;
     idist_config cfg{};
     uint32_t n = 0, dim = 0;
@@ -1373,7 +1375,7 @@ static void run_combined(const idist_index* idx, idist_search_ctx* ctx, std::vec
     idist_status st = IDIST_OK;
     if (k == 1) {
         st = search_batch_impl(idx, ctx, b[0]->q, 1, b[0]->pid, b[0]->dist, b[0]->cnt, b[0]->ctr);
-    } else if (!idx->comb_ctx[slot] && (st = idist_search_ctx_new(idx, 0, &idx->comb_ctx[slot])) != IDIST_OK) {
+    } else if (!idx->comb_ctx[slot] && (st = idist_search_ctx_new(idx, kCombineBatch, &idx->comb_ctx[slot])) != IDIST_OK) {   // backed for a full batch at once: growing a context later would synchronise the device under everybody's feet
         // (reported to every caller of the batch below)
     } else {
         ctx = idx->comb_ctx[slot];
