@@ -26,7 +26,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // tile, K chunk, LDS pitch: 36 floats = 16-B aligned rows, and 36 = 4 * 9 with 9 odd, so 16 lanes reading float4s of rows
 // that differ mod 16 hit 64 distinct banks (ds_read_b128 / ds_write_b128 conflict-free)
-constexpr int kTM = 128, kTN = 128, kKC = 32, kLDP = 36;
+#ifndef IDIST_MFMA_KC
+#define IDIST_MFMA_KC 32
+#endif
+constexpr int kTM = 128, kTN = 128, kKC = IDIST_MFMA_KC, kLDP = kKC + 4;   // (36 and 68 = 4 * odd)
+constexpr int kKF4 = kKC / 4;                         // float4s per row and chunk
+constexpr int kStageF4 = kTM * kKF4 / 256;            // float4s a thread stages per matrix and chunk
 
 // |row|^2 in storage order (one wave per row)
 __global__ __launch_bounds__(64) void row_norms_kernel(const float* __restrict__ rows, uint32_t n, uint32_t stride,
@@ -80,15 +85,15 @@ __global__ __launch_bounds__(256) void mfma_dist_kernel(MfmaArgs a) {
         for (int j = 0; j < 2; j++)
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    // K loop: one 32-float chunk of the 128 query rows and the 128 point rows per iteration.  The next chunk is requested
-    // (global -> registers) before the current one's 64 MFMAs per wave, operands move as float4s, and inside a chunk
-    // instruction #j contracts elements j (lanes 0-31) and 16 + j (lanes 32-63), so a lane's sixteen operands of a row
-    // are contiguous.  (Stored rows are a multiple of 16 floats: a chunk is full or half full, the rest is zero.)
-    auto fetch = [&](uint32_t kc, float4 (&va)[4], float4 (&vb)[4]) {
+    // K loop: one kKC-float chunk of the 128 query rows and the 128 point rows per iteration.  The next chunk is requested
+    // (global -> registers) before the current one's MFMAs (2 * kKC per wave), operands move as float4s, and inside a
+    // chunk instruction #j contracts elements j (lanes 0-31) and kKC / 2 + j (lanes 32-63), so a lane's operands of a row
+    // are contiguous.  (Stored rows are a multiple of 16 floats: the last chunk may be partly zero.)
+    auto fetch = [&](uint32_t kc, float4 (&va)[kStageF4], float4 (&vb)[kStageF4]) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = tid + 256 * u;                                // 1024 float4 = 128 rows x 8
-            const int row = idx >> 3, part = (idx & 7) << 2;
+        for (int u = 0; u < kStageF4; u++) {
+            const int idx = tid + 256 * u;                                // 128 rows x kKF4 float4
+            const int row = idx / kKF4, part = (idx % kKF4) << 2;
             va[u].x = va[u].y = va[u].z = va[u].w = 0.0f;
             vb[u] = va[u];
             if (kc + (uint32_t)part < a.stride) {
@@ -100,22 +105,22 @@ __global__ __launch_bounds__(256) void mfma_dist_kernel(MfmaArgs a) {
             }
         }
     };
-    float4 pa[4], pb[4];
+    float4 pa[kStageF4], pb[kStageF4];
     fetch(0u, pa, pb);
     for (uint32_t kc = 0; kc < a.stride; kc += kKC) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kStageF4; u++) {
             const int idx = tid + 256 * u;
-            const int off = (idx >> 3) * kLDP + ((idx & 7) << 2);
+            const int off = (idx / kKF4) * kLDP + ((idx % kKF4) << 2);
             *reinterpret_cast<float4*>(As + off) = pa[u];
             *reinterpret_cast<float4*>(Bs + off) = pb[u];
         }
         __syncthreads();
         if (kc + kKC < a.stride) fetch(kc + kKC, pa, pb);
-        const float* ap = As + (wr * 64 + (lane & 31)) * kLDP + 16 * (lane >> 5);
-        const float* bp = Bs + (wc * 64 + (lane & 31)) * kLDP + 16 * (lane >> 5);
+        const float* ap = As + (wr * 64 + (lane & 31)) * kLDP + (kKC / 2) * (lane >> 5);
+        const float* bp = Bs + (wc * 64 + (lane & 31)) * kLDP + (kKC / 2) * (lane >> 5);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < kKC / 8; q++) {
             const float4 a0 = *reinterpret_cast<const float4*>(ap + 4 * q);
             const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * kLDP + 4 * q);
             const float4 b0 = *reinterpret_cast<const float4*>(bp + 4 * q);

@@ -13,6 +13,10 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 import instant_distance_amd as ida  # noqa: E402
+from instant_distance_amd import _capi  # noqa: E402
+
+if os.environ.get("PB_LIB"):          # an alternative build of the library (A/B of a kernel change in one box session)
+    _capi._singleton = _capi.Lib(os.path.join(ROOT, "instant-distance_amd", "csrc", os.environ["PB_LIB"]))
 
 dev = torch.device("cuda", 0)
 n, dim, nq = 1_000_000, 768, 4096
