@@ -30,11 +30,27 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# one hardware queue per host thread of the scalar-call measurement (libidist sets the same default when it is the first HIP
-# user of a process; here torch starts the runtime, so it has to be in the environment before `import torch`)
+# one hardware queue per host thread of the scalar-call measurement: a process-wide runtime setting, the HOST's to make (libidist
+# does not touch the environment) and read once when the HIP runtime starts — so before `import torch`
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md chip table: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def source_stamp():
+    """The commit the tree under test was built from: `.build_commit` (written by __graft_entry__.build() / scripts/stamp.py,
+    which travels to the GPU box — .git does not), else `git rev-parse` where a repository is at hand."""
+    try:
+        return open(os.path.join(ROOT, ".build_commit")).read().strip()
+    except OSError:
+        pass
+    try:
+        import subprocess
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True, timeout=10).stdout.strip()
+        return (sha + ("+dirty" if dirty else "")) if sha else None
+    except Exception:  # noqa: BLE001
+        return None
 
 # BASELINE.json configs (SURVEY.md §8d).  nq: queries per GPU per step ("weak") or of the whole job ("strong": C5's
 # 65,536-query batch is split over the GPUs).  gtq: queries with exact ground truth.  cpu_build: prefix the CPU oracle builds.
@@ -130,7 +146,9 @@ def scalar_calls(hnsw, ida, q_host, n_threads, calls):
         t.join()
     if errs:
         raise RuntimeError(f"idist_search_batch failed in a thread: status {errs}")
-    scalar_calls.kernel_ms = float(np.mean([s.kernel_times_ms(32).mean() for s in searches]))   # HIP events of the last launches
+    kts = [s.kernel_times_ms(32) for s in searches]                # HIP events of the launches that served the last calls
+    kts = [k.mean() for k in kts if len(k)]
+    scalar_calls.kernel_ms = float(np.mean(kts)) if kts else None
     return n_threads * calls / dt
 
 
@@ -154,6 +172,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="add the `checks` object (size-independent properties; used by tests/)")
     ap.add_argument("--threads", default="1,4,16", help="host-thread counts of the scalar-call measurement ('' = skip)")
     ap.add_argument("--max-batch", type=int, default=0)
+    ap.add_argument("--no-inproc-rccl", action="store_true", help="N > 1: skip the in-process idist_replicate_rccl measurement after the run")
     args = ap.parse_args()
     cfgd = CONFIGS[args.config]
 
@@ -297,6 +316,35 @@ def main():
         elapsed = float(t.item())
     search.check_status()
 
+    # ---- N > 1: a bad broadcast must fail loudly.  Every rank answers the SAME sample (the head of the global batch) on its
+    # own replica; rank 0's answers are the yardstick (and are themselves checked against the CPU oracle below): one u64
+    # digest of ids + distance bits + counts + work counters is broadcast and compared on every rank.
+    replica_check = None
+    if world > 1:
+        rs_n = min(512, nq_total)
+        d_sample = synth(torch, nq_total, dim, 123456790, dev)[:rs_n].contiguous()
+        so = (torch.empty(rs_n, chosen, dtype=torch.int32, device=dev), torch.empty(rs_n, chosen, dtype=torch.float32, device=dev),
+              torch.empty(rs_n, dtype=torch.int32, device=dev), torch.empty(rs_n, 3, dtype=torch.int32, device=dev))
+        s2_ = ida.Search()
+        hnsw.search_batch_device(s2_, d_sample.data_ptr(), rs_n, so[0].data_ptr(), so[1].data_ptr(), so[2].data_ptr(), so[3].data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        s2_.check_status()
+        import hashlib
+        hsh = hashlib.blake2b(digest_size=8)
+        sample_np = [t.cpu().numpy() for t in so]
+        for arr in sample_np:
+            hsh.update(np.ascontiguousarray(arr).tobytes())
+        mine = int.from_bytes(hsh.digest(), "little") >> 1          # 63 bits: fits a signed int64 tensor
+        ref = torch.tensor([mine], dtype=torch.int64, device=dev)
+        dist.broadcast(ref, src=0)
+        same = torch.tensor([1 if int(ref.item()) == mine else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        if not bool(same.item()):
+            raise SystemExit(f"rank {rank}: replica answers differ from rank 0's on the {rs_n}-query sample (digest {mine:#x} vs "
+                             f"{int(ref.item()):#x}): the replicated index is not the built one")
+        replica_check = {"queries": rs_n, "all_ranks_identical_to_rank0": True, "digest": f"{mine:#x}"}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = nq_total / (elapsed / args.steps)
@@ -351,7 +399,7 @@ def main():
         thr = {}
         for T in [int(x) for x in args.threads.split(",") if x]:
             thr[str(T)] = {"gpu_calls_per_s": round(scalar_calls(hnsw, ida, q_host, T, max(200, 1600 // T)), 1),
-                           "gpu_kernel_ms_mean": round(scalar_calls.kernel_ms, 4)}
+                           "gpu_kernel_ms_mean": None if scalar_calls.kernel_ms is None else round(scalar_calls.kernel_ms, 4)}
         single["threads"] = thr
         hnsw.search_batch(q_host, search)
         t0 = time.perf_counter()
@@ -387,6 +435,21 @@ def main():
             avail_gb = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) / 2**20
         except Exception:  # noqa: BLE001
             avail_gb = 1e9
+        if not args.no_cpu_baseline and world > 1 and avail_gb >= need_gb:
+            # N > 1: no CPU timing (rank 0 at N = 1 only), but the yardstick of the replica check is itself held against the
+            # oracle: rank 0's answers for the sample == the oracle's on the exported graph
+            from oracle import pyoracle as po
+            zero, layers = hnsw.into_parts()
+            oix = po.Index.from_arrays(d_pts.cpu().numpy(), zero, layers, po.default_config(ef_search=chosen), borrow=True)
+            o = oix.search(d_sample.cpu().numpy(), threads=effective_cores())
+            ok = bool(np.array_equal(o.pid, sample_np[0].astype(np.uint32)) and np.array_equal(o.dist.view(np.uint32), sample_np[1].view(np.uint32))
+                      and np.array_equal(o.count, sample_np[2].astype(np.uint32)) and np.array_equal(o.counters, sample_np[3].astype(np.uint32)))
+            replica_check["rank0_identical_to_oracle"] = ok
+            if not ok:
+                raise SystemExit("rank 0: GPU answers for the replica-check sample differ from the CPU oracle's on the exported graph")
+            parity = {"queries": replica_check["queries"], f"ef{chosen}": ok, "all_identical": ok,
+                      "note": "N > 1: rank 0's answers for the replica-check sample against the oracle on the exported graph"}
+            del oix, zero, layers
         if not args.no_cpu_baseline and world == 1 and avail_gb < need_gb:
             parity = {"skipped": f"the oracle needs the points on the host: {need_gb:.0f} GB, {avail_gb:.0f} GB available"}
         elif not args.no_cpu_baseline and world == 1:
@@ -450,7 +513,8 @@ def main():
                    "seconds": round(tc, 2), "ids_identical_to_gpu": same,
                    "ids_distance_bits_counts_and_work_counters_identical_to_gpu": same_all}
 
-        out = {"metric": f"queries/sec @ recall@10>=0.95, {'1M' if n == 1_000_000 else n}x{dim}-d f32; index build points/sec",
+        out = {"commit": source_stamp(),
+               "metric": f"queries/sec @ recall@10>=0.95, {'1M' if n == 1_000_000 else n}x{dim}-d f32; index build points/sec",
                "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if split else "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -463,14 +527,48 @@ def main():
                           "replication": replication, "replicate_seconds": round(t_rep, 3), **rep},
                "build": build, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "single_query": single,
                "pcie_inclusive": pcie}
+        if replica_check is not None:
+            out["replica_check"] = replica_check
         if checks is not None:
             out["checks"] = checks
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 2)
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        hung = False
+        if world > 1 and not args.no_inproc_rccl:
+            # The C ABI's own replication (idist_replicate_rccl: one process, ncclCommInitAll over the devices, one grouped
+            # ncclBroadcast per buffer) next to the torch.distributed path above — measured when the other ranks are gone
+            # and their GPUs are free again, on a watchdog so that the line is printed whatever RCCL does.
+            res = {}
+
+            def inproc():
+                try:
+                    reps = hnsw.replicate(list(range(1, world)), rccl=True)
+                    secs = hnsw.last_replicate_seconds
+                    got = reps[-1].search_batch(sample_q_host, ida.Search(), counters=True)
+                    same = bool(np.array_equal(got.pid, sample_np[0].astype(np.uint32)) and
+                                np.array_equal(got.distance.view(np.uint32), sample_np[1].view(np.uint32)) and
+                                np.array_equal(got.counters, sample_np[3].astype(np.uint32)))
+                    res.update({"seconds": round(secs, 3), "destinations": world - 1,
+                                "GBps_per_destination": round(rep["replicate_bytes"] / max(secs, 1e-9) / 1e9, 2),
+                                "last_replica_answers_identical_to_rank0": same,
+                                "note": "idist_replicate_rccl from ONE process after the per-rank processes exited; communicator set-up excluded"})
+                    del reps
+                except Exception as e:  # noqa: BLE001
+                    res.update({"error": repr(e)[:300]})
+
+            sample_q_host = d_sample.cpu().numpy()
+            th = threading.Thread(target=inproc, daemon=True)
+            th.start()
+            th.join(timeout=240)
+            hung = th.is_alive()
+            out["config"]["replicate_rccl_in_process"] = {"skipped": "no answer within 240 s"} if hung else res
+        print(json.dumps(out), flush=True)
+        if hung:
+            os._exit(0)
 
 
 if __name__ == "__main__":

@@ -74,7 +74,7 @@ enum {
     IDIST_ERR_HIP = 3,            /* HIP runtime error, see idist_last_error() */
     IDIST_ERR_UNSUPPORTED = 4,    /* option the GPU engine does not implement (yet) */
     IDIST_ERR_BAD_GRAPH = 5,      /* imported adjacency violates the reference's invariants */
-    IDIST_ERR_TIE_OVERFLOW = 6,   /* > IDIST tie capacity equidistant live candidates */
+    IDIST_ERR_TIE_OVERFLOW = 6,   /* device-pointer launches only: the tie region overflowed, enqueue the batch again (idist_config.tie_policy) */
     IDIST_ERR_INTERNAL = 7        /* device-side guard tripped */
 };
 
@@ -100,24 +100,24 @@ typedef struct idist_config {
                                    deterministic contract = reference with one rayon thread);
                                    0 = library default; k = at most k concurrent inserts per
                                    step (the rayon for_each of core/lib.rs:316-318). */
-    int32_t tie_policy;         /* IDIST_TIES_*: what to do when more than 64 un-expanded candidates sit
-                                   exactly at the furthest distance of a full `nearest` (mass duplicates,
-                                   dense integer grids).  The reference's heap is unbounded; the engine's
-                                   tie region is not.  STRICT (default): fail with
-                                   IDIST_ERR_TIE_OVERFLOW — a result is either the reference's or an error.
-                                   DROP: keep the 64 smallest (distance, pid) ties, never expand the
-                                   others, and go on — deterministic, flagged in idist_build_stats /
+    int32_t tie_policy;         /* IDIST_TIES_*: what happens when more un-expanded candidates sit exactly at the furthest
+                                   distance of a full `nearest` than the engine's tie region holds (mass duplicates, dense
+                                   integer grids).  The reference's candidate heap is unbounded (core/lib.rs:564).
+                                   STRICT (default): the result is ALWAYS the reference's.  The region grows on demand — a
+                                   build that overflows is repeated with 8x the region, a host-pointer search batch is
+                                   searched again with 4x — and beyond 4096 entries the ties that do not fit go to a bag
+                                   in HBM and come back in (distance, pid) order: unbounded like the reference's heap, slow
+                                   only on data that needs it.  IDIST_ERR_TIE_OVERFLOW is returned in ONE place only:
+                                   idist_search_ctx_status after a device-pointer launch (idist_search_batch_device cannot
+                                   re-run a launch it did not wait for); that context uses the larger region / the bags
+                                   from its next launch on, so the caller enqueues the same batch again.
+                                   DROP: keep the configured region, never expand the ties that do not fit, go on —
+                                   deterministic, flagged in idist_build_stats.tie_overflow /
                                    idist_search_ctx_tie_overflowed, no longer bit-identical on such data. */
-    uint32_t tie_capacity;      /* size of that tie region, 0 = 64 (the default), at most 4096.  It lives in LDS
-                                   next to `nearest` (8 B per entry): a larger one keeps such data bit-identical
-                                   to the reference at the price of fewer resident waves per CU.  STRICT enlarges
-                                   it by itself: a build that overflows is repeated with 8x the region, a
-                                   host-pointer search batch with 4x (the device-pointer variant reports the
-                                   overflow through idist_search_ctx_status and uses the larger region from the
-                                   next launch on); beyond 4096 entries the ties that do not fit go to a bag in HBM
-                                   (n keys per query slot, as many slots as fit 1 GiB) and come back in (distance, pid)
-                                   order — unbounded like the reference's BinaryHeap (core/lib.rs:564), slow only on
-                                   data that needs it. */
+    uint32_t tie_capacity;      /* initial size of that tie region, 0 = 64 (the default), at most 4096.  It lives in LDS
+                                   next to `nearest` (8 B per entry): a larger one spares such data the repeated launch at
+                                   the price of fewer resident waves per CU.  (HBM bags: n keys per query slot, as many
+                                   slots as fit 1 GiB.) */
 } idist_config;
 
 typedef struct idist_index idist_index;

@@ -30,19 +30,24 @@
 
 using namespace idist;
 
-#ifndef IDIST_EMU
-// The reference's concurrency model is one `Search` per host thread on a shared index (core/lib.rs:352-356): every context
-// owns a stream, and the one-workgroup kernels of scalar calls only overlap if those streams sit on different hardware
-// queues.  The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES queues (default 4) and reads the
-// variable when it starts: 16 threads reach 6.3k calls/s on 4 queues, 14.3k on 16 (profiles/probe_r03b_scalar_calls_*).
-// Set it — unless the host already did — when the library is loaded, i.e. before its first HIP call.
-__attribute__((constructor)) static void idist_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
-#endif
+// (The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues — default 4, read once when the
+// runtime starts.  One `Search` per host thread = one stream per thread: a host that runs more than four of them sets
+// GPU_MAX_HW_QUEUES itself before its first HIP call; this library does not touch the environment.)
 
 namespace {
 
 thread_local std::string g_err;
 thread_local struct idist_progress* g_watch = nullptr;   // armed by idist_progress_watch_next_build
+
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
 
 idist_status fail(idist_status st, const char* fmt, ...) {
     char buf[512];
@@ -146,9 +151,11 @@ struct ScalarReq {
     uint32_t* ctr;
     idist_status st = IDIST_OK;
     std::string err;
+    float kernel_ms = -1.0f;         // HIP-event duration of the launch that served this call (< 0: events are off)
     bool done = false, lead = false;
     int slot = -1;
     std::condition_variable cv;
+    void fail() { st = IDIST_ERR_INTERNAL; err = "the combined launch serving this call threw (out of host memory?)"; }
 };
 
 struct idist_index {
@@ -256,6 +263,14 @@ struct idist_search_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0[IDIST_EVENT_RING] = {nullptr}, ev1[IDIST_EVENT_RING] = {nullptr};
     uint64_t n_launch = 0;
+    // Kernel times this context reports (idist_search_ctx_kernel_times): one record per call served, in call order — its own
+    // launches (slot of the event ring; resolved when asked for) and the calls that rode along in another thread's launch
+    // (the leader hands the measured duration back, ScalarReq::kernel_ms)
+    struct TimeRec { int32_t slot; float ms; };    // slot >= 0: own launch, event pair `slot`; slot < 0: `ms` measured elsewhere
+    TimeRec recs[IDIST_EVENT_RING] = {};
+    uint64_t n_rec = 0;
+    int32_t device = 0;            // copies of what growing the context needs: nothing is read through `idx` after creation
+    int n_cu = 256;
     Knobs knobs;
     // staging for the host-pointer API
     float* d_q = nullptr;
@@ -356,14 +371,14 @@ idist_status load_points_host(idist_index* ix, const float* h_nat) {
     return s;
 }
 
-uint32_t default_slots(const idist_index* ix) {
+uint32_t default_slots(uint32_t n_points, int n_cu) {
     // fill the chip (16 single-wave workgroups per CU) within a memory budget for the visited bitmaps: one bit per
     // point and slot (core/types.rs:13-59), i.e. 512 MB for 4096 slots at 1M points, 5 GB at 10M
     size_t freeb = 0, totalb = 0;
     if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) freeb = (size_t)8 << 30;
     const size_t budget = std::min<size_t>(freeb / 3, (size_t)64 << 30);
-    const size_t vis = (size_t)vis_geometry(ix->n).slot_words * 4;
-    size_t s = (size_t)ix->n_cu * 16;
+    const size_t vis = (size_t)vis_geometry(n_points).slot_words * 4;
+    size_t s = (size_t)n_cu * 16;
     if (vis) s = std::min(s, std::max<size_t>(budget / vis, 64));
     return (uint32_t)std::max<size_t>(s, 1);
 }
@@ -491,13 +506,21 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     const uint32_t a_waves_max = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)((160u * 1024u) / smem)));
     a_waves = std::min(a_waves, a_waves_max);
     uint32_t* d_zero2 = nullptr;
-    hipStream_t s1 = nullptr, s2 = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr;
     hipEvent_t evA[2] = {nullptr, nullptr}, evS[2] = {nullptr, nullptr};
+    // The descents of odd and even steps run on streams of their own (pipelined schedule): step k + 1's descents depend on
+    // the updates of step k - 1 only, so they may start while step k's are still draining — the tail of every launch (a
+    // few hundred waves finishing their last item while the rest of the chip idles, ~6 % of a step) is filled by the next
+    // step's first items, and in the growth phase of a layer (steps narrower than the chip) two steps' descents simply run
+    // side by side.  Everything a descent launch owns is kept per parity: visited bitmaps, work-queue head, the step-A
+    // outputs.  IDIST_BUILD_A_STREAMS=1: one descent stream (round 3's schedule; same graphs).
+    bool two_a = !tie_spill && !(getenv("IDIST_BUILD_A_STREAMS") && getenv("IDIST_BUILD_A_STREAMS")[0] == '1');
     auto release = [&]() {
         hipFree(d_zero2);
         hipFree(d_ext_work);
         if (s1) hipStreamDestroy(s1);
         if (s2) hipStreamDestroy(s2);
+        if (s3) hipStreamDestroy(s3);
         for (int i = 0; i < 2; i++) { if (evA[i]) hipEventDestroy(evA[i]); if (evS[i]) hipEventDestroy(evS[i]); }
         hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount); hipFree(d_dlog_log); hipFree(d_dlog_pd);
         hipFree(d_vis); hipFree(d_tie_spill); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
@@ -514,8 +537,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         }                                                                                           \
     } while (0)
     if (ext) BCHK(hipMalloc((void**)&d_ext_work, (size_t)ext_cap * 8));
-    BCHK(hipMalloc((void**)&d_vis, (size_t)slots * vg.slot_words * 4));
-    BCHK(hipMemset(d_vis, 0, (size_t)slots * vg.slot_words * 4));
+    two_a = two_a && pipe;
+    const size_t vis_words = (size_t)slots * vg.slot_words;            // one set of visited bitmaps per descent stream
+    BCHK(hipMalloc((void**)&d_vis, vis_words * 4 * (two_a ? 2 : 1)));
+    BCHK(hipMemset(d_vis, 0, vis_words * 4 * (two_a ? 2 : 1)));
     if (tie_spill) BCHK(hipMalloc((void**)&d_tie_spill, (size_t)slots * n * 8));
     BCHK(hipMalloc((void**)&d_nbr_dist, (size_t)n * IDIST_M2 * 4));
     BCHK(hipMemset(d_nbr_dist, 0, (size_t)n * IDIST_M2 * 4));
@@ -535,6 +560,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         BCHK(hipMemset(d_zero2, 0xFF, (size_t)n * IDIST_M2 * 4));
         BCHK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
         BCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        if (two_a) BCHK(hipStreamCreateWithFlags(&s3, hipStreamNonBlocking));
         for (int i = 0; i < 2; i++) { BCHK(hipEventCreate(&evA[i])); BCHK(hipEventCreate(&evS[i])); }
     }
     BCHK(hipMalloc((void**)&d_edge_pid, n_edges * 4));
@@ -623,7 +649,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             a.count = B;
             const uint64_t k = n_batches + 1;                              // step number, 1-based
             const int par = (int)(k & 1u);
-            hipStream_t sA = pipe ? s1 : stream, sS = pipe ? s2 : stream;
+            hipStream_t sA = pipe ? (two_a && par ? s3 : s1) : stream, sS = pipe ? s2 : stream;
             IndexView viewA = view, viewS = view;
             BuildArgs aA = a;
             if (pipe) {
@@ -632,15 +658,16 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
                 // taken from it (s1 has waited for it already), and a descent that enters the zero layer through a
                 // node of that last step must find its row, not the all-INVALID one of the older copy.
                 const int lag = B > 1 && !first_of_layer ? 2 : 1;
-                if (k > (uint64_t)lag) BCHK(hipStreamWaitEvent(s1, evS[(k - lag) & 1u], 0));
+                if (k > (uint64_t)lag) BCHK(hipStreamWaitEvent(sA, evS[(k - lag) & 1u], 0));
                 viewA.zero = zbuf[(k - lag) & 1u];
                 viewS.zero = zbuf[par];
-                aA.queue = d_small + 1;
+                aA.queue = d_small + (two_a && par ? 48 : 1);             // step A queue head, one per descent stream
+                if (two_a && par) aA.visited = d_vis + vis_words;
                 aA.dlog_log = d_dlog_log + (((size_t)par * cap) << dl_shift);
                 aA.dlog_pd = d_dlog_pd + (((size_t)par * cap) << (dl_shift + 1u));
                 aA.wbuf = d_wbuf + (size_t)par * cap * cfg.ef_construction;
                 aA.wcount = d_wcount + (size_t)par * cap;
-                BCHK(hipMemsetAsync(d_small, 0, 8, sA));                  // step A queue head
+                BCHK(hipMemsetAsync(aA.queue, 0, 4, sA));
             } else {
                 BCHK(hipMemsetAsync(d_small, 0, 32, sA));                 // n_touched, queue heads, n_slow
             }
@@ -652,6 +679,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             BuildArgs aS = aA;                                             // same step-A outputs, own counters
             aS.queue = smallS + 1;
             aS.n_slow = smallS + 3;
+            aS.visited = d_vis;
             BuildArgs af = aS;
             af.efc = no_fast ? 0u : cfg.ef_construction;                  // efc = 0 makes the fast kernel defer everything
 #define LAUNCH_BUILD(NB_, RS_, TAIL_)                                                              \
@@ -678,7 +706,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         else if (classic) { IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA); }                    \
         else { IDIST_LAUNCH(kAo, gridA, 64, smem, sA, viewA, aA); }                                \
         if (pipe) {                                                                                \
-            BCHK(hipEventRecord(evA[par], s1));                                                    \
+            BCHK(hipEventRecord(evA[par], sA));                                                    \
             BCHK(hipStreamWaitEvent(s2, evA[par], 0));                                             \
             IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s2, zbuf[par ^ 1], zbuf[par], a.touched, smallS, prev_start, prev_count); \
             BCHK(hipMemsetAsync(smallS, 0, 32, s2));                                               \
@@ -707,8 +735,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         if (layer > 0) {                                                 // UpperNode::from_zero, :323-328
             const size_t total = (size_t)end * IDIST_M;
             const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
-            if (pipe && n_batches) BCHK(hipStreamWaitEvent(s1, evS[n_batches & 1u], 0));   // the layer is complete
-            IDIST_LAUNCH(snapshot_kernel, grid, 256, 0, stream, zbuf[n_batches & 1u], ix->d_upper + ix->layer_off[layer - 1] * IDIST_M, end);
+            // pipelined: behind the layer's last step on the update stream; the event the next steps' descents wait for
+            // (the last step's) is recorded again behind it, so whichever stream they run on finds the snapshot taken
+            IDIST_LAUNCH(snapshot_kernel, grid, 256, 0, pipe ? s2 : stream, zbuf[n_batches & 1u], ix->d_upper + ix->layer_off[layer - 1] * IDIST_M, end);
+            if (pipe) BCHK(hipEventRecord(evS[n_batches & 1u], s2));       // (both the first and the second step of the next layer wait for this one)
         }
     }
     if (pipe) {
@@ -754,6 +784,12 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // the reference's own count exists only where every selection ran in the reference's order
     ix->stats.n_heur_ref = (ext || (cfg.has_heuristic && no_fast && !a2_mfma && cap == 1)) ? stats[8] : 0;
     if (prog) { prog->slot[0] = n; prog->slot[1] = 0; }
+#ifdef IDIST_PROBE
+    fprintf(stderr, "{\"probe\": \"step_B_lookups\", \"n\": %u, \"updates_single_new\": %llu, \"updates_general\": %llu, \"lookups\": %llu, "
+            "\"misses\": %llu, \"misses_member_of_previous_step\": %llu, \"misses_member_of_this_step\": %llu, \"new_vs_new_rows\": %llu, "
+            "\"n_updates\": %llu, \"n_updates_full\": %llu, \"n_sel_pairs\": %llu, \"n_heur_rows\": %llu}\n",
+            n, stats[9], stats[10], stats[11], stats[12], stats[13], stats[14], stats[15], stats[5], stats[7], stats[3], stats[4]);
+#endif
     ix->stats.tie_overflow = (small[6] & kStTieOverflow) ? 1 : 0;
     return device_status_to_code(small[6], cfg.tie_policy);
 }
@@ -805,7 +841,7 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
     uint32_t s = 1;
     while (s < want) s <<= 1;                                    // few distinct sizes: powers of two up to the cap ...
     if (ctx->slots) s = std::max(s, ctx->slots * 8u);            // ... and at least 8x per step: growing synchronises the device
-    const uint32_t cap = ctx->slots_req ? ctx->slots_req : default_slots(ctx->idx);
+    const uint32_t cap = ctx->slots_req ? ctx->slots_req : default_slots(ctx->n_points, ctx->n_cu);
     s = std::max(std::min(s, cap), 1u);
     if (s <= ctx->slots) return IDIST_OK;
     const size_t bytes = std::max<size_t>((size_t)s * ctx->vis.slot_words * 4, 256);
@@ -988,6 +1024,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     if (ctx->knobs.events) {
         HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
         ctx->n_launch++;
+        ctx->recs[ctx->n_rec++ % IDIST_EVENT_RING] = {(int32_t)slot, 0.0f};
     }
     return IDIST_OK;
 }
@@ -1246,6 +1283,8 @@ idist_status idist_search_ctx_new(const idist_index* idx, uint32_t slots, idist_
     c->base_tie_cap = tie_capacity(idx->cfg);
     c->n_points = idx->n;
     c->stride = idx->L.stride;
+    c->device = idx->device;
+    c->n_cu = idx->n_cu;
     auto bail = [&](hipError_t e) {
         idist_search_ctx_free(c);
         return fail(IDIST_ERR_HIP, "search ctx allocation failed: %s", hipGetErrorString(e));
@@ -1289,7 +1328,9 @@ void idist_search_ctx_free(idist_search_ctx* c) {
 
 idist_status idist_search_ctx_reserve(idist_search_ctx* ctx, uint32_t slots) {
     if (!ctx) return fail(IDIST_ERR_INVALID_ARG, "ctx is null");
-    // (the index is only read for its device: a context outlives nothing it points to, see check_ctx)
+    // the bitmaps belong on the context's own device whatever device the calling thread has current (replicas on several
+    // GPUs); device, CU count and point count were copied at creation — the index itself is not touched (it may be gone)
+    HIPCHK(hipSetDevice(ctx->device));
     const uint32_t cap = ctx->slots_req ? ctx->slots_req : 0xFFFFFFFFu;
     CHK(ensure_slots(ctx, std::min(std::max(slots, 1u), cap), ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));                   // the new bitmaps are cleared before any stream may use them
@@ -1343,24 +1384,24 @@ idist_status idist_search_ctx_tie_overflowed(idist_search_ctx* ctx, int32_t* out
     return IDIST_OK;
 }
 
+static idist_status resolve_time(idist_search_ctx* ctx, const idist_search_ctx::TimeRec& r, float* ms) {
+    if (r.slot < 0) { *ms = r.ms; return IDIST_OK; }
+    HIPCHK(hipEventSynchronize(ctx->ev1[r.slot]));
+    HIPCHK(hipEventElapsedTime(ms, ctx->ev0[r.slot], ctx->ev1[r.slot]));
+    return IDIST_OK;
+}
+
 idist_status idist_search_ctx_last_kernel_ms(idist_search_ctx* ctx, float* ms) {
     if (!ctx || !ms) return fail(IDIST_ERR_INVALID_ARG, "null argument");
-    if (!ctx->n_launch) return fail(IDIST_ERR_INVALID_ARG, "no search kernel has been launched on this ctx");
-    const uint32_t slot = (uint32_t)((ctx->n_launch - 1) % IDIST_EVENT_RING);
-    HIPCHK(hipEventSynchronize(ctx->ev1[slot]));
-    HIPCHK(hipEventElapsedTime(ms, ctx->ev0[slot], ctx->ev1[slot]));
-    return IDIST_OK;
+    if (!ctx->n_rec) return fail(IDIST_ERR_INVALID_ARG, "no search kernel has been timed for this ctx (IDIST_KERNEL_EVENTS=0, or no call yet)");
+    return resolve_time(ctx, ctx->recs[(ctx->n_rec - 1) % IDIST_EVENT_RING], ms);
 }
 
 idist_status idist_search_ctx_kernel_times(idist_search_ctx* ctx, float* ms, uint32_t cap, uint32_t* n_out) {
     if (!ctx || !ms || !n_out) return fail(IDIST_ERR_INVALID_ARG, "null argument");
-    const uint64_t have = std::min<uint64_t>(ctx->n_launch, IDIST_EVENT_RING);
+    const uint64_t have = std::min<uint64_t>(ctx->n_rec, IDIST_EVENT_RING);
     const uint32_t take = (uint32_t)std::min<uint64_t>(have, cap);
-    for (uint32_t i = 0; i < take; i++) {
-        const uint32_t slot = (uint32_t)((ctx->n_launch - take + i) % IDIST_EVENT_RING);
-        HIPCHK(hipEventSynchronize(ctx->ev1[slot]));
-        HIPCHK(hipEventElapsedTime(&ms[i], ctx->ev0[slot], ctx->ev1[slot]));
-    }
+    for (uint32_t i = 0; i < take; i++) CHK(resolve_time(ctx, ctx->recs[(ctx->n_rec - take + i) % IDIST_EVENT_RING], &ms[i]));
     *n_out = take;
     return IDIST_OK;
 }
@@ -1391,8 +1432,11 @@ static void run_combined(const idist_index* idx, idist_search_ctx* ctx, std::vec
                 if (b[i]->ctr) memcpy(b[i]->ctr, ctr.data() + (size_t)i * 3, 12);
             }
     }
+    float kms = -1.0f;
+    if (st == IDIST_OK && k > 1 && ctx->n_rec) (void)resolve_time(ctx, ctx->recs[(ctx->n_rec - 1) % IDIST_EVENT_RING], &kms);
     for (ScalarReq* r : b) {
         r->st = st;
+        r->kernel_ms = kms;
         if (st != IDIST_OK) r->err = g_err;
     }
 }
@@ -1411,10 +1455,14 @@ idist_status idist_search_batch(const idist_index* idx, idist_search_ctx* ctx, c
     if (!out_pid || !out_dist) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
     // The reference's scalar call, possibly from many threads at once (one Search each, core/lib.rs:352-356): beyond eight
     // launches in flight on this index a call rides along in another thread's launch instead of making its own
-    if (nq == 1 && ctx->knobs.combine) {
+    // (IDIST_TIES_DROP: idist_search_ctx_tie_overflowed is a per-context answer about the caller's OWN queries — such calls
+    // always launch on their own context.  Strict ties: where the escalated region / the bags live is unobservable.)
+    if (nq == 1 && ctx->knobs.combine && idx->cfg.tie_policy != IDIST_TIES_DROP) {
         ScalarReq r{queries, out_pid, out_dist, out_count, out_counters};
         idx->comb.submit(r, [&](std::vector<ScalarReq*>& b, int slot) { run_combined(idx, ctx, b, slot); });
         if (r.st != IDIST_OK) g_err = r.err;
+        // a call that rode along (or led company) ran on a slot context: its kernel time is reported through the caller's own
+        else if (r.kernel_ms >= 0.0f) ctx->recs[ctx->n_rec++ % IDIST_EVENT_RING] = {-1, r.kernel_ms};
         return r.st;
     }
     return search_batch_impl(idx, ctx, queries, nq, out_pid, out_dist, out_count, out_counters);
@@ -1437,7 +1485,9 @@ static idist_status search_batch_impl(const idist_index* idx, idist_search_ctx* 
             if (ctx->h_io) hipHostFree(ctx->h_io);
             ctx->h_io = nullptr;
             ctx->io_cap = 0;
-            HIPCHK(hipHostMalloc((void**)&ctx->h_io, cap, hipHostMallocPortable | hipHostMallocMapped));
+            // coherent (fine-grained) on purpose: the host polls the completion word and reads the results WHILE the stream is
+            // still busy — with a non-coherent mapping (HIP_HOST_COHERENT=0) they would only be visible at kernel end
+            HIPCHK(hipHostMalloc((void**)&ctx->h_io, cap, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
             if (hipHostGetDevicePointer((void**)&ctx->d_io, ctx->h_io, 0) != hipSuccess) ctx->d_io = ctx->h_io;
             ctx->io_cap = cap;
         }
@@ -1474,8 +1524,9 @@ static idist_status search_batch_impl(const idist_index* idx, idist_search_ctx* 
                 }
                 bool seen = false;
                 for (uint64_t spins = 0; !(seen = (*h_done == seq)); spins++) {
-                    __builtin_ia32_pause();
-                    if ((spins & 0xFFFFu) == 0xFFFFu &&
+                    if (spins < 2048u) cpu_relax();
+                    else std::this_thread::yield();               // 64+ waiting threads must not keep the leaders off the cores
+                    if ((spins & 0x3FFFu) == 0x3FFFu &&
                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);

@@ -33,7 +33,8 @@ public:
     }
     unsigned max_leaders() const { return max_leaders_; }
 
-    // Req needs: bool done, lead (both false on entry), int slot, std::condition_variable cv.  Returns after r.done.
+    // Req needs: bool done, lead (both false on entry), int slot, std::condition_variable cv, void fail() (called instead of a
+    // result when run() threw: nothing propagates out of submit, which sits under a C ABI).  Returns after r.done.
     template <class Run>
     void submit(Req& r, Run&& run) {
         std::unique_lock<std::mutex> lk(mu_);
@@ -52,9 +53,17 @@ public:
         batch.push_back(&r);
         take_pending(batch);
         lk.unlock();
-        run(batch, slot);
+        // run() may throw (it allocates staging buffers): the riders of this batch are parked on their condition variables
+        // and the slot is ours — whatever happens they are woken with a status and the slot moves on
+        bool threw = false;
+        try {
+            run(batch, slot);
+        } catch (...) {
+            threw = true;
+        }
         lk.lock();
         for (Req* q : batch) {
+            if (threw) q->fail();
             q->done = true;
             if (q != &r) q->cv.notify_one();
         }

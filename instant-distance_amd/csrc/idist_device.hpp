@@ -220,6 +220,97 @@ __device__ __forceinline__ void dist_rounds_inflight(const IndexView& ix, const 
     }
 }
 
+// The same for ANY dimension (`trait Point` is dimension-agnostic, core/lib.rs:780-782): the row geometry (nb full blocks,
+// rs remaining chain steps, tail) is read at run time, and what is fixed at compile time is the register tile — RIF rounds
+// of 8 rows in flight, each row cut into groups of CH blocks (CH float4 per lane).  Two groups are in flight at any time:
+// group c + 1 of every round is requested before group c is consumed, so a wave keeps 2 * RIF * 8 rows * CH * 128 B on the
+// wire whatever the row length (the compile-time geometries issue a whole row up front, which only fits the register file
+// up to 768-d).  A chain still sees its operands in row order — group after group, block after block — so the arithmetic
+// is the compile-time variants' bit for bit.  The query fragment comes from LDS (one ds_read_b128 per block, shared by
+// the RIF rows of a lane).
+template <int CH, int RIF, int RSTEP = 8, class Mid = NoMid>
+__device__ __forceinline__ void dist_rounds_inflight_rt(const IndexView& ix, const VecView qv, const uint32_t* act_pid,
+                                                        uint32_t* act_dist, int na, int first = 0, Mid mid = Mid()) {
+    const int lane = lane_id();
+    const int g = lane >> 3, j = lane & 7;
+    const int nb = (int)ix.nb, rs = (int)ix.rs;
+    const bool tail = ix.tail != 0;
+    for (int base = first; base < na; base += RSTEP * RIF) {
+        const float* row[RIF];
+        bool on[RIF];
+#pragma unroll
+        for (int r = 0; r < RIF; r++) {
+            const int k = base + RSTEP * r + g;
+            on[r] = k < na;
+            row[r] = ix.points + (size_t)act_pid[on[r] ? k : first] * ix.stride + j * 4;   // (idle groups re-read a live row: never used)
+        }
+        float4 A[RIF][CH], B[RIF][CH];
+        auto load = [&](float4 (&dst)[RIF][CH], int t0) {
+#pragma unroll
+            for (int u = 0; u < CH; u++)
+                if (t0 + u < nb) {                                   // wave-uniform: a scalar branch
+#pragma unroll
+                    for (int r = 0; r < RIF; r++)
+                        if (on[r]) dst[r][u] = ldg_row4(row[r] + (t0 + u) * 32);
+                }
+        };
+        float acc[RIF];
+#pragma unroll
+        for (int r = 0; r < RIF; r++) acc[r] = 0.0f;
+        auto eat = [&](const float4 (&src)[RIF][CH], int t0) {
+#pragma unroll
+            for (int u = 0; u < CH; u++)
+                if (t0 + u < nb) {
+                    const float4 w = *reinterpret_cast<const float4*>(qv.blk + (t0 + u) * qv.bstride + j * 4);
+#pragma unroll
+                    for (int r = 0; r < RIF; r++) {
+                        if (!on[r]) continue;
+                        float d;
+                        d = w.x - src[r][u].x; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                        d = w.y - src[r][u].y; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                        d = w.z - src[r][u].z; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                        d = w.w - src[r][u].w; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                    }
+                }
+        };
+        load(A, 0);
+        // the steps that do not fill a block and the 4-wide tail: at most four dwords per row, requested with the first group
+        float pr[RIF][3], pt[RIF];
+#pragma unroll
+        for (int r = 0; r < RIF; r++) {
+            const float* rem = row[r] - j * 4 + nb * 32;
+#pragma unroll
+            for (int c = 0; c < 3; c++) pr[r][c] = (on[r] && c < rs) ? rem[c * 8 + j] : 0.0f;
+            pt[r] = (on[r] && tail) ? rem[rs * 8 + (j & 3)] : 0.0f;
+        }
+        if (nb > CH) load(B, CH);
+        if (base == first) mid();
+        for (int t0 = 0; t0 < nb; t0 += 2 * CH) {
+            eat(A, t0);
+            if (t0 + 2 * CH < nb) load(A, t0 + 2 * CH);
+            if (t0 + CH < nb) {
+                eat(B, t0 + CH);
+                if (t0 + 3 * CH < nb) load(B, t0 + 3 * CH);
+            }
+        }
+        float qr[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) qr[c] = c < rs ? qv.rem[c * 8 + j] : 0.0f;
+        const float qt = tail ? qv.rem[rs * 8 + (j & 3)] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < RIF; r++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (c < rs) {                                        // py/lib.rs:391-396, steps not filling a block
+                    const float d = qr[c] - pr[r][c];
+                    acc[r] = __builtin_fmaf(d, d, acc[r]);
+                }
+            const float res = fold_chains(acc[r], tail && on[r], qt, pt[r]);
+            if (on[r] && j == 0) act_dist[base + RSTEP * r + g] = canon_bits(res, ix.metric);
+        }
+    }
+}
+
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void dist_rounds(const IndexView& ix, const float* q, const uint32_t* act_pid,
                                             uint32_t* act_dist, int na);
@@ -259,14 +350,22 @@ __device__ __forceinline__ void dist_rounds(const IndexView& ix, const VecView q
                     }
                 }
             } else {
-                for (int t = 0; t < nb; t++) {
-                    const float4 p = ldg_row4(row + t * 32 + j * 4);
-                    const float4 w = *reinterpret_cast<const float4*>(qv.blk + t * qv.bstride + j * 4);
-                    float d;
-                    d = w.x - p.x; acc = __builtin_fmaf(d, d, acc);
-                    d = w.y - p.y; acc = __builtin_fmaf(d, d, acc);
-                    d = w.z - p.z; acc = __builtin_fmaf(d, d, acc);
-                    d = w.w - p.w; acc = __builtin_fmaf(d, d, acc);
+                // any dimension: eight blocks (1 KB of the row per 8-lane group) requested together, then consumed in order
+                for (int t0 = 0; t0 < nb; t0 += 8) {
+                    float4 p[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (t0 + u < nb) p[u] = ldg_row4(row + (t0 + u) * 32 + j * 4);
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (t0 + u < nb) {
+                            const float4 w = *reinterpret_cast<const float4*>(qv.blk + (t0 + u) * qv.bstride + j * 4);
+                            float d;
+                            d = w.x - p[u].x; acc = __builtin_fmaf(d, d, acc);
+                            d = w.y - p[u].y; acc = __builtin_fmaf(d, d, acc);
+                            d = w.z - p[u].z; acc = __builtin_fmaf(d, d, acc);
+                            d = w.w - p[u].w; acc = __builtin_fmaf(d, d, acc);
+                        }
                 }
             }
             for (int c = 0; c < rs; c++) {   // py/lib.rs:391-396, steps not filling a block
@@ -298,8 +397,8 @@ __device__ __forceinline__ void dist_rounds_quad(const IndexView& ix, const floa
         if (8 * wv >= na) mid();                               // no row for this wave: the loop body never runs
         dist_rounds_inflight<NB, RS, TAIL, 2, true, 32>(ix, natural_view(q, NB), act_pid, act_dist, na, 8 * wv, mid);
     } else {
-        mid();
-        dist_rounds<NB, RS, TAIL>(ix, natural_view(q, (int)ix.nb), act_pid, act_dist, na, 8 * wv, 32);
+        if (8 * wv >= na) mid();
+        dist_rounds_inflight_rt<8, 2, 32>(ix, natural_view(q, (int)ix.nb), act_pid, act_dist, na, 8 * wv, mid);
     }
 }
 
@@ -346,11 +445,19 @@ constexpr int rounds_in_flight() {
     if (walk_mode(WALK) == kWalkLatency) return NB <= 4 ? 8 : (NB <= 12 ? IDIST_RIF9 : (NB <= 24 ? 2 : 1));
     return NB <= 12 ? IDIST_RIF_OVERLAP : (NB <= 24 ? IDIST_RIF24_OVERLAP : 1);
 }
+// register tile of the runtime geometry (dist_rounds_inflight_rt) by the kernel's register budget: one fat wave per SIMD
+// (512 registers) keeps 2 x 4 rounds x 8 blocks = 256 data registers = 64 KB on the wire; two waves per SIMD (256
+// registers: the build's descents) 2 x 3 x 4 = 96; the many-small-waves bitmap walks 2 x 2 x 4 = 64
+template <int WALK> constexpr int rt_rounds() { return walk_waves(WALK) == 1 ? 4 : (walk_waves(WALK) == 2 ? 3 : 2); }
+template <int WALK> constexpr int rt_blocks() { return walk_waves(WALK) == 1 ? 8 : 4; }
 template <int NB, int RS, int TAIL, int WALK, class Mid = NoMid>
 __device__ __forceinline__ void dist_rounds_walk(const IndexView& ix, const float* q, const uint32_t* act_pid,
                                                  uint32_t* act_dist, int na, Mid mid = Mid()) {
     constexpr int RIF = rounds_in_flight<NB, WALK>();
-    if constexpr (RIF > 1 || (walk_rif(WALK) == 1 && NB >= 0)) {
+    if constexpr (NB < 0 && walk_mode(WALK) != kWalkClassic) {
+        if (na <= 0) mid();
+        dist_rounds_inflight_rt<rt_blocks<WALK>(), rt_rounds<WALK>()>(ix, natural_view(q, (int)ix.nb), act_pid, act_dist, na, 0, mid);
+    } else if constexpr (RIF > 1 || (walk_rif(WALK) == 1 && NB >= 0)) {
         if (na <= 0) mid();
         dist_rounds_inflight<NB, RS, TAIL, RIF, !walk_q_lds(WALK)>(ix, natural_view(q, NB), act_pid, act_dist, na, 0, mid);
     } else {
@@ -905,12 +1012,31 @@ constexpr uint32_t kDlogMiss = 0xFFFFFFFFu;            // never a canonical dist
 struct DistLog {
     uint64_t* log;      // HBM [ids the set holds]: dist_bits << 32 | index in the set; nullptr = nothing is logged
     uint32_t n;         // entries (wave-uniform)
+    // Quotient form: the set holds twice as many entries as it has dwords, so its distances are sorted through its LDS in
+    // two halves (dlog_publish_q16).  The log is kept in two halves as well — entries with index < half at log[0 ..), the
+    // others at log[half ..) (an index is logged at most once per layer, so neither half can overflow) — and each pass of
+    // the publication reads only the entries it scatters.  half = 0: one log (the id form).
+    uint32_t half = 0, n_hi = 0;
+    __device__ __forceinline__ void reset() { n = 0; n_hi = 0; }
 };
 // wave-collective: lanes with idx >= 0 (the id's index in the on-chip set) log their distance
 __device__ __forceinline__ void dlog_append(DistLog& L, int idx, uint32_t dist_bits) {
     const uint64_t m = __ballot(idx >= 0);
     if (!m) return;
-    if (idx >= 0) L.log[L.n + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = ((uint64_t)dist_bits << 32) | (uint32_t)idx;
+    const uint64_t below = (1ull << lane_id()) - 1ull;
+    const uint64_t e = ((uint64_t)dist_bits << 32) | (uint32_t)idx;
+    if (L.half) {
+        const bool hi = idx >= (int)L.half;
+        const uint64_t mh = __ballot(idx >= 0 && hi), ml = m & ~mh;
+        if (idx >= 0) {
+            if (hi) L.log[L.half + L.n_hi + (uint32_t)__popcll(mh & below)] = e;
+            else L.log[L.n + (uint32_t)__popcll(ml & below)] = e;
+        }
+        L.n += (uint32_t)__popcll(ml);
+        L.n_hi += (uint32_t)__popcll(mh);
+        return;
+    }
+    if (idx >= 0) L.log[L.n + (uint32_t)__popcll(m & below)] = e;
     L.n += (uint32_t)__popcll(m);
 }
 // End of the descent: the set goes out in its published form, one 32-B record per bucket = its four ids followed by
@@ -959,19 +1085,23 @@ __device__ __forceinline__ void dlog_publish_q16(const DistLog& L, const Visited
     for (uint32_t i = lane; i < nbuck; i += 64) o[4u * i] = t[i];
     visited_drain();                                       // the log's own stores have landed before it is read back
     wave_sync();
-    constexpr int kDeep = 8;
+    // log entries per lane in flight: one round trip per 1024 entries (a descent logs ~5k: three trips per half where eight
+    // entries per lane over the whole log, twice, took twenty — a tenth of a descent's time with nothing else in flight)
+    constexpr int kDeep = 16;
     for (uint32_t h = 0; h < 2u; h++) {
-        for (uint32_t base = 0; base < L.n; base += 64u * kDeep) {
+        const uint64_t* lg = L.log + (L.half ? h * L.half : 0u);
+        const uint32_t cnt = L.half ? (h ? L.n_hi : L.n) : L.n;
+        for (uint32_t base = 0; base < cnt; base += 64u * kDeep) {
             uint64_t e[kDeep];
 #pragma unroll
             for (int u = 0; u < kDeep; u++) {
                 const uint32_t i = base + 64u * (uint32_t)u + (uint32_t)lane;
-                e[u] = L.log[i < L.n ? i : 0u];
+                e[u] = lg[i < cnt ? i : 0u];
             }
 #pragma unroll
             for (int u = 0; u < kDeep; u++) {
                 const uint32_t idx = (uint32_t)e[u];
-                if (base + 64u * (uint32_t)u + (uint32_t)lane < L.n && idx / half == h) v.tab[idx - h * half] = (uint32_t)(e[u] >> 32);
+                if (base + 64u * (uint32_t)u + (uint32_t)lane < cnt && idx / half == h) v.tab[idx - h * half] = (uint32_t)(e[u] >> 32);
             }
         }
         wave_sync();

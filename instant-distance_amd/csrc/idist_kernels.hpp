@@ -481,7 +481,7 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
             for (int i = lane; i < st.plen; i += 64) visited_mark(vis, (uint32_t)st.W[i]);
             visited_added(vis, (uint32_t)st.plen);
             wave_sync();
-            dl.n = 0;                                             // the set was emptied: its indices start over
+            dl.reset();                                           // the set was emptied: its indices start over
             if (dl.log)
                 for (int i0 = 0; i0 < st.plen; i0 += 64) {
                     const bool on = i0 + lane < st.plen;
@@ -528,14 +528,21 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         if (a.tie_spill) { st.spill = a.tie_spill + (size_t)slot * a.tie_spill_cap; st.spill_cap = a.tie_spill_cap; }
         // only the heuristic's re-selections look distances up
         DistLog dl{a.has_heuristic && a.use_dlog ? a.dlog_log + ((size_t)item << a.dl_shift) : nullptr, 0u};
+        if constexpr (walk_vis16(LAT)) dl.half = 4u << (a.tab_log2 - 2u);     // dwords of the set = entries of one half
         insert_descent<NB, RS, TAIL, LAT>(ix, a, sm, st, vis, nw_pid, tot, dl);
         const int nw = st.plen < st.ef ? st.plen : st.ef;             // Search.nearest
+        // (the hand-over addresses below depend on nothing but the item: hipcc computed them up here and kept them in
+        // scratch across the whole walk — an opaque copy of the item pins their computation to where they are used)
+        uint32_t item_l = item;
+#ifndef IDIST_EMU
+        asm volatile("" : "+s"(item_l));
+#endif
         if (a.has_heuristic) {
             // select_heuristic (:470-472) runs in step A2 with the selected rows on chip; hand Search.nearest over
-            for (int i = lane; i < nw; i += 64) a.wbuf[(size_t)item * a.efc + i] = st.W[i] & kKeyMask;
-            if (lane == 0) a.wcount[item] = (uint32_t)nw;
+            for (int i = lane; i < nw; i += 64) a.wbuf[(size_t)item_l * a.efc + i] = st.W[i] & kKeyMask;
+            if (lane == 0) a.wcount[item_l] = (uint32_t)nw;
             if (dl.log) {
-                uint32_t* pd = a.dlog_pd + ((size_t)item << (a.dl_shift + 1u));
+                uint32_t* pd = a.dlog_pd + ((size_t)item_l << (a.dl_shift + 1u));
                 if constexpr (walk_vis16(LAT)) dlog_publish_q16(dl, vis, pd);
                 else dlog_publish(dl, vis, pd);
             }
@@ -963,6 +970,12 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
     const uint32_t ntouched = *a.n_touched;
     HeurCounters hc{0, 0};
     uint32_t updates = 0, deferred = 0, status = 0;
+#ifdef IDIST_PROBE
+    // measurement build (make probe): where step B's distance look-ups miss.  [0] single-new-point updates, [1] general-path
+    // updates, [2] look-ups, [3] misses, [4] ... of members that joined in the previous step, [5] ... in this step, [6] rows
+    // gathered for the new-vs-new columns of the general path
+    uint32_t pb[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     // items per dequeue: 37 M updates through one counter would cost ~0.4 s; small steps keep 1 item per wave
     uint32_t kChunk = a.chunk ? a.chunk : ntouched / (gridDim.x * 4u);
     kChunk = kChunk < 1u ? 1u : (kChunk > 16u ? 16u : kChunk);
@@ -1031,6 +1044,13 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             uint32_t dn = selL ? dn_spec : kDlogMiss;        // d(new, selected entry of this lane), requested before the inbox walk
             const bool miss = selL && dn == kDlogMiss;
             const uint64_t mm = __ballot(miss);
+#ifdef IDIST_PROBE
+            pb[0] += 1;
+            pb[2] += (uint32_t)__popcll(__ballot(selL));
+            pb[3] += (uint32_t)__popcll(mm);
+            pb[4] += (uint32_t)__popcll(__ballot(miss && cur < a.start && cur + a.count >= a.start));
+            pb[5] += (uint32_t)__popcll(__ballot(miss && cur >= a.start));
+#endif
             if (mm) {
                 const int n0 = __popcll(mm), at = __popcll(mm & below);
                 if (miss) act_p[at] = cur;
@@ -1130,6 +1150,14 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
                 // columns [0, ns0) that missed + the other new points: gather those rows
                 const uint64_t mm = __ballot(lane < ns0 && dv == kDlogMiss);
                 const int n0 = __popcll(mm);
+#ifdef IDIST_PROBE
+                if (ai == 0) pb[1] += 1;
+                pb[2] += (uint32_t)ns0;
+                pb[3] += (uint32_t)n0;
+                pb[4] += (uint32_t)__popcll(__ballot(lane < ns0 && dv == kDlogMiss && X[lane] < a.start && X[lane] + a.count >= a.start));
+                pb[5] += (uint32_t)__popcll(__ballot(lane < ns0 && dv == kDlogMiss && X[lane] >= a.start));
+                pb[6] += (uint32_t)k_new;
+#endif
                 if (lane < ns0 && dv == kDlogMiss) {
                     const int at = __popcll(mm & ((1ull << lane) - 1ull));
                     act_x[at] = (uint32_t)lane;
@@ -1272,6 +1300,9 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
     }
     if (lane == 0) {
         if (status) atomicOr(a.status, status);
+#ifdef IDIST_PROBE
+        for (int i = 0; i < 7; i++) if (pb[i]) atomicAdd(&a.stats[9 + i], (unsigned long long)pb[i]);
+#endif
         if (updates | deferred) {
             atomicAdd(&a.stats[3], (unsigned long long)hc.n_dist);
             atomicAdd(&a.stats[4], (unsigned long long)hc.n_rows);

@@ -514,7 +514,26 @@ typedef struct {
     ido_search** pool;          /* pairs */
     size_t pool_len, pool_cap;
     ido_counters total;
+    struct helpers_s* helpers;  /* threads < 0 only: sequential insertions, one insertion's neighbour updates on helper threads */
 } construction_t;
+
+/* threads = -k (test infrastructure for LARGE exact builds): the insertions stay strictly sequential in PointId order —
+ * the exact contract — but the <= 64 neighbour updates of ONE insertion (core/lib.rs:481-516) run on k threads.  With
+ * extend_candidates = false they are independent: iteration i reads points, the row of found[i].pid and `new`, and
+ * rewrites only that row, so any interleaving gives the bytes of the serial loop (tests pin threads=-k == threads=1).
+ * Each thread owns its `insertion` Search; their work counters are summed. */
+typedef struct helpers_s {
+    int k;                        /* threads, the caller included */
+    pthread_t* th;
+    pthread_barrier_t bar;
+    ido_search** ins;             /* [k] */
+    construction_t* C;
+    uint32_t nw;
+    const cand_t* found;
+    size_t nfound;
+    atomic_uint next;
+    int stop;
+} helpers_t;
 
 static void pool_pop(construction_t* C, ido_search** a, ido_search** b) {
     pthread_mutex_lock(&C->pool_mu);
@@ -579,6 +598,38 @@ static void zeronode_insert(uint32_t* row, size_t idx, uint32_t pid) {
     row[idx] = pid;
 }
 
+static void add_neighbor_heuristic(ido_search* s, uint32_t nw, const uint32_t* current, uint32_t ncur, const layer_t* L,
+                                   const float* point, const pts_t* P, int extend, int keep);
+
+/* core/lib.rs:484-496 for found[i] (heuristic, extend_candidates = false), run by thread t of the helper pool */
+static void helpers_job(helpers_t* H, int t) {
+    construction_t* C = H->C;
+    ido_index* ix = C->ix;
+    layer_t Lz = {ix->zero, IDO_M2, NULL};
+    uint32_t cur_row[IDO_M2];
+    for (;;) {
+        uint32_t i = atomic_fetch_add(&H->next, 1);
+        if (i >= H->nfound) break;
+        uint32_t pid = H->found[i].pid;
+        uint32_t* prow = ix->zero + (size_t)pid * IDO_M2;
+        const float* old = ix->points + (size_t)pid * ix->dim;
+        uint32_t ncur = layer_row(&Lz, pid, cur_row);
+        add_neighbor_heuristic(H->ins[t], H->nw, cur_row, ncur, &Lz, old, &C->P, 0, ix->cfg.keep_pruned);
+        zeronode_rewrite(prow, H->ins[t]->nearest.a, H->ins[t]->nearest.len);
+    }
+}
+typedef struct { helpers_t* H; int t; } helper_arg_t;
+static void* helpers_main(void* arg) {
+    helper_arg_t* a = (helper_arg_t*)arg;
+    for (;;) {
+        pthread_barrier_wait(&a->H->bar);                 /* a job is posted (or stop) */
+        if (a->H->stop) break;
+        helpers_job(a->H, a->t);
+        pthread_barrier_wait(&a->H->bar);                 /* every row of this insertion is rewritten */
+    }
+    return NULL;
+}
+
 /* Construction::insert, core/lib.rs:437-528 */
 static void construction_insert(construction_t* C, uint32_t nw, uint32_t layer) {
     ido_index* ix = C->ix;
@@ -621,6 +672,20 @@ static void construction_insert(construction_t* C, uint32_t nw, uint32_t layer) 
     }
 
     uint32_t cur_row[IDO_M2];
+    if (C->helpers && cfg->has_heuristic && !cfg->extend_candidates) {
+        helpers_t* H = C->helpers;                        /* :481-496 on k threads, see helpers_t */
+        H->nw = nw; H->found = found; H->nfound = nfound;
+        atomic_store(&H->next, 0);
+        pthread_barrier_wait(&H->bar);
+        helpers_job(H, 0);
+        pthread_barrier_wait(&H->bar);
+        for (int t = 0; t < H->k; t++) {                  /* their distance calls are this insertion's */
+            insertion->ctr.n_heur += H->ins[t]->ctr.n_heur + H->ins[t]->ctr.n_dist;
+            memset(&H->ins[t]->ctr, 0, sizeof(H->ins[t]->ctr));
+        }
+        for (size_t i = 0; i < nfound; i++) node[i] = own[i] = found[i].pid;   /* node.set(i,pid), :516 */
+        nfound = 0;                                       /* nothing left for the serial loop */
+    }
     for (size_t i = 0; i < nfound; i++) {                 /* :481 */
         float distance = found[i].distance;
         uint32_t pid = found[i].pid;
@@ -653,9 +718,11 @@ static void construction_insert(construction_t* C, uint32_t nw, uint32_t layer) 
     }
     /* the reference writes `node` under a write lock held since :438; other
      * threads only observe it after release => publish the row at the end. */
-    if (C->locks) node_lock(&C->locks[nw]);
-    for (size_t i = 0; i < nfound; i++) node[i] = own[i];
-    if (C->locks) node_unlock(&C->locks[nw]);
+    if (C->locks) {
+        node_lock(&C->locks[nw]);
+        for (size_t i = 0; i < nfound; i++) node[i] = own[i];
+        node_unlock(&C->locks[nw]);
+    }
 
     pool_push(C, search, insertion);                      /* :527 */
 }
@@ -711,6 +778,20 @@ ido_index* ido_build(const float* points, uint32_t n, uint32_t dim, const ido_co
         C.locks = (atomic_flag*)malloc((size_t)n * sizeof(atomic_flag));
         for (uint32_t i = 0; i < n; i++) atomic_flag_clear(&C.locks[i]);
     }
+    helpers_t H;
+    helper_arg_t* hargs = NULL;
+    if (threads < -1) {                                   /* sequential insertions, helper threads inside one insertion */
+        memset(&H, 0, sizeof(H));
+        H.k = -threads;
+        H.C = &C;
+        H.ins = (ido_search**)malloc(sizeof(ido_search*) * (size_t)H.k);
+        for (int t = 0; t < H.k; t++) { H.ins[t] = search_with_capacity(n); H.ins[t]->ef = cfg->ef_construction; }
+        pthread_barrier_init(&H.bar, NULL, (unsigned)H.k);
+        H.th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)H.k);
+        hargs = (helper_arg_t*)malloc(sizeof(helper_arg_t) * (size_t)H.k);
+        for (int t = 1; t < H.k; t++) { hargs[t].H = &H; hargs[t].t = t; pthread_create(&H.th[t], NULL, helpers_main, &hargs[t]); }
+        C.helpers = &H;
+    }
 
     /* ranges, :275-281: layer L gets pids [max(start,1), cum[L]) */
     for (int32_t layer = (int32_t)top; layer >= 0; layer--) { /* :304 */
@@ -735,6 +816,14 @@ ido_index* ido_build(const float* points, uint32_t n, uint32_t dim, const ido_co
             ix->layers[layer - 1] = up;
             ix->layer_len[layer - 1] = end;
         }
+    }
+    if (C.helpers) {
+        H.stop = 1;
+        pthread_barrier_wait(&H.bar);
+        for (int t = 1; t < H.k; t++) pthread_join(H.th[t], NULL);
+        for (int t = 0; t < H.k; t++) ido_search_free(H.ins[t]);
+        pthread_barrier_destroy(&H.bar);
+        free(H.ins); free(H.th); free(hargs);
     }
     for (size_t i = 0; i < C.pool_len; i++) ido_search_free(C.pool[i]);
     free(C.pool);

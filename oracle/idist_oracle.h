@@ -79,7 +79,11 @@ void ido_permutation(uint64_t seed, uint32_t n, uint32_t* out_pid, uint32_t* ord
  * threads == 1 : pid-ascending sequential insertion — the exact contract
  *                (= reference with RAYON_NUM_THREADS=1).
  * threads  > 1 : per-layer parallel-for with per-node locks, mirrors
- *                core/lib.rs:316-318 (non-deterministic, timing only). */
+ *                core/lib.rs:316-318 (non-deterministic, timing only).
+ * threads < -1 : the exact contract again — insertions strictly sequential — with the <= 64 independent neighbour
+ *                updates of one insertion (core/lib.rs:481-516, extend_candidates = false) on |threads| threads: the
+ *                same bytes as threads == 1 (tests/test_oracle_golden.py pins that), minutes instead of tens of
+ *                minutes for the 100k-point exact-build tests. */
 ido_index* ido_build(const float* points, uint32_t n, uint32_t dim,
                      const ido_config* cfg, int threads, ido_counters* counters);
 

@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -13,8 +14,9 @@
 
 struct Req {
     int q = 0, out = -1, served = 0, slot = -1;
-    bool done = false, lead = false;
+    bool done = false, lead = false, failed = false;
     std::condition_variable cv;
+    void fail() { failed = true; }
 };
 
 int main(int argc, char** argv) {
@@ -22,7 +24,11 @@ int main(int argc, char** argv) {
     const unsigned max_leaders = argc > 3 ? (unsigned)atoi(argv[3]) : 4;
     const size_t max_batch = argc > 4 ? (size_t)atoi(argv[4]) : 6;
     idist::Combiner<Req> comb(max_leaders, max_batch);
+    // 6th argument: every k-th launch throws (std::bad_alloc in the real run()): its whole batch must come back failed, nobody
+    // may be left waiting, the slot must move on
+    const int throw_every = argc > 5 ? atoi(argv[5]) : 0;
     std::atomic<int> in_flight{0}, max_in_flight{0}, launches{0}, bad{0};
+    std::atomic<long> failed{0};
     std::atomic<long> served{0}, widest{0};
     std::vector<std::atomic<int>> slot_busy(max_leaders);
     for (auto& x : slot_busy) x = 0;
@@ -37,7 +43,12 @@ int main(int argc, char** argv) {
                 const int now = ++in_flight;
                 int m = max_in_flight.load();
                 while (now > m && !max_in_flight.compare_exchange_weak(m, now)) {}
-                launches++;
+                const int nth = ++launches;
+                if (throw_every && nth % throw_every == 0) {
+                    slot_busy[slot] = 0;
+                    --in_flight;
+                    throw std::bad_alloc();
+                }
                 long w = widest.load();
                 while ((long)b.size() > w && !widest.compare_exchange_weak(w, (long)b.size())) {}
                 std::this_thread::sleep_for(std::chrono::microseconds(200 + (r.q % 7) * 20));
@@ -46,7 +57,8 @@ int main(int argc, char** argv) {
                 slot_busy[slot] = 0;
                 --in_flight;
             });
-            if (!r.done || r.served != 1 || r.out != r.q * 2 + 1) bad++;
+            if (r.failed) { failed++; if (!r.done || r.served != 0) bad++; }
+            else if (!r.done || r.served != 1 || r.out != r.q * 2 + 1) bad++;
         }
     };
     std::vector<std::thread> ts;
@@ -55,7 +67,8 @@ int main(int argc, char** argv) {
     const long total = (long)T * calls;
     printf("threads %d calls %ld served %ld launches %d max_in_flight %d widest_batch %ld bad %d\n", T, total, served.load(), launches.load(),
            max_in_flight.load(), widest.load(), bad.load());
-    if (bad || served != total) return 1;
+    printf("failed (thrown launches) %ld\n", failed.load());
+    if (bad || served + failed != total || (throw_every == 0 && failed) || (throw_every && !failed)) return 1;
     if (max_in_flight > (int)max_leaders) return 2;
     if (T > 2 * (int)max_leaders && launches >= total) return 3;        // with more threads than leaders, calls must combine
     if (T <= (int)max_leaders && launches != total) return 4;           // with no more threads than leaders, every call launches itself

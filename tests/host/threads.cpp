@@ -20,6 +20,8 @@
     } while (0)
 
 int main(int argc, char** argv) {
+    // one hardware queue per searching thread's stream: the host's setting, made before the first HIP call
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 20000, dim = argc > 2 ? (uint32_t)atoi(argv[2]) : 96;
     const int T = argc > 3 ? atoi(argv[3]) : 16, calls = argc > 4 ? atoi(argv[4]) : 100;
     std::mt19937 rng(7);

@@ -188,7 +188,7 @@ static inline hipError_t hipMalloc(void** p, size_t n) {
     return hipSuccess;
 }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-enum { hipHostMallocPortable = 1, hipHostMallocMapped = 2 };
+enum { hipHostMallocPortable = 1, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }

@@ -10,10 +10,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("threads,calls,leaders,batch", [(32, 150, 4, 6), (3, 200, 4, 6), (64, 60, 8, 96), (9, 300, 1, 2), (16, 100, 8, 3)])
-def test_combiner_serves_every_request_once_and_never_deadlocks(tmp_path, threads, calls, leaders, batch):
+@pytest.mark.parametrize("threads,calls,leaders,batch,throw_every", [(32, 150, 4, 6, 0), (3, 200, 4, 6, 0), (64, 60, 8, 96, 0), (9, 300, 1, 2, 0),
+                                                                     (16, 100, 8, 3, 0), (32, 150, 4, 6, 7), (9, 300, 1, 2, 3)])
+def test_combiner_serves_every_request_once_and_never_deadlocks(tmp_path, threads, calls, leaders, batch, throw_every):
     exe = str(tmp_path / "combine_test")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(ROOT, "tests", "host", "combine_test.cpp"), "-o", exe])
-    out = subprocess.run([exe, str(threads), str(calls), str(leaders), str(batch)], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([exe, str(threads), str(calls), str(leaders), str(batch), str(throw_every)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "combiner ok" in out.stdout

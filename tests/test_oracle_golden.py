@@ -201,3 +201,22 @@ def test_bruteforce_matches_numpy(oracle):
         d = np.array([oracle.distance(q[i], p) for p in pts])
         order = np.lexsort((np.arange(300), d))[:10]
         assert np.array_equal(order.astype(np.uint32), pid[i])
+
+
+@pytest.mark.parametrize("n,dim,kind,kw", [(2500, 24, "uniform", {}), (2000, 16, "lowrank", {"keep_pruned": 0}),
+                                           (1500, 3, "grid", {"metric": 1, "ef_construction": 30}), (700, 300, "uniform", {}),
+                                           (900, 5, "uniform", {"has_heuristic": 0})])
+def test_helper_thread_build_is_the_sequential_build(oracle, n, dim, kind, kw):
+    """`threads = -k` (oracle/idist_oracle.h): insertions strictly sequential, the <= 64 independent neighbour updates of one
+    insertion on k threads — what the 100k-point exact-build tests compare the GPU with.  It must BE the threads = 1 build:
+    same zero / upper arrays, same work counters (and a plain serial build where the option does not apply)."""
+    import parity_cases as pc
+
+    pts = pc.gen_points(np.random.default_rng(n), n, dim, kind)
+    cfg = oracle.default_config(**kw)
+    a = oracle.Index.build(pts, cfg, threads=1)
+    b = oracle.Index.build(pts, cfg, threads=-5)
+    assert np.array_equal(a.zero, b.zero) and len(a.layers) == len(b.layers)
+    assert all(np.array_equal(x, y) for x, y in zip(a.layers, b.layers))
+    ca, cb = a.build_counters, b.build_counters
+    assert (ca.n_dist, ca.n_exp0, ca.n_expU, ca.n_heur) == (cb.n_dist, cb.n_exp0, cb.n_expU, cb.n_heur)

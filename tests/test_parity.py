@@ -64,15 +64,13 @@ def test_search_parity_heavy_ties(eng, oracle):
     h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().metric(1).ef_search(20))
     q = rng.integers(0, 3, size=(S(kind, 8, 200), 4)).astype(np.float32)
     want = oix.search(q)
+    # the default (strict) policy never answers with an error here: a host-pointer batch that overflows the 64-entry tie
+    # region is searched again with a larger one (and, past 4096 entries, with the HBM bags) until it IS the reference's
     for _, lat in pc.SEARCH_VARIANTS:
-        try:
-            with pc.search_variant(lat):
-                got = h.search_batch(q, ida.Search(), counters=True)
-        except ida.IdistError as e:          # > 64 live equidistant candidates is reported, never silent
-            assert e.status == 6
-            continue
+        with pc.search_variant(lat):
+            got = h.search_batch(q, ida.Search(), counters=True)
         pc.check_search_result(got, want)
-    # with a larger tie region (idist_config.tie_capacity) the same data must match the reference, no error allowed
+    # with a larger tie region requested up front (idist_config.tie_capacity) the same
     hb = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().metric(1).ef_search(20).tie_capacity(2048))
     for _, lat in pc.SEARCH_VARIANTS:
         with pc.search_variant(lat):
@@ -552,11 +550,8 @@ def test_fuzz_search_and_exact_build_emulated(engine_loader, oracle, case):
 def test_fuzz_search_and_exact_build_gpu(engine_loader, oracle, case):
     ida = engine_loader("gpu")
     c = _fuzz_cases("gpu", 14, 78)[case]
-    try:
-        pc.check_search_parity(ida, oracle, n=c["n"], dim=c["dim"], ef_search=c["ef"], metric=c["metric"], kind=c["kind"],
-                               nq=96, seed=c["seed"], ef_construction=c["efc"])
-    except ida.IdistError as e:      # integer grids in low dimension can exceed the tie capacity: reported, never silent
-        assert e.status == 6 and c["kind"] == "grid"
+    pc.check_search_parity(ida, oracle, n=c["n"], dim=c["dim"], ef_search=c["ef"], metric=c["metric"], kind=c["kind"],
+                           nq=96, seed=c["seed"], ef_construction=c["efc"])
     pc.check_build_exact(ida, oracle, n=min(c["n"], 1500), dim=c["dim"], metric=c["metric"], kind=c["kind"],
                          ef_construction=c["efc"], keep_pruned=c["keep"], seed=c["seed"] + 1)
 
@@ -567,11 +562,8 @@ def test_fuzz_concurrent_build_gpu(engine_loader, oracle, case):
     ida = engine_loader("gpu")
     c = _fuzz_cases("gpu", 5, 79)[case]
     n = c["n"] * (12 if c["dim"] <= 128 else 6)
-    try:
-        pc.check_build_concurrent_invariants(ida, oracle, n=n, dim=c["dim"], kind=c["kind"], metric=c["metric"],
-                                             ef_construction=max(c["efc"], 40), keep_pruned=c["keep"], seed=c["seed"])
-    except ida.IdistError as e:      # dense integer grids: > 64 live equidistant candidates is reported, never silent
-        assert e.status == 6 and c["kind"] == "grid" and c["dim"] <= 8
+    pc.check_build_concurrent_invariants(ida, oracle, n=n, dim=c["dim"], kind=c["kind"], metric=c["metric"],
+                                         ef_construction=max(c["efc"], 40), keep_pruned=c["keep"], seed=c["seed"])
 
 
 def test_concurrent_build_invariants_emulated(engine_loader, oracle):

@@ -1,0 +1,87 @@
+"""Parity at sizes the small cases cannot reach (`-m gpu` only).
+
+  * `Hnsw::new` / `Construction::insert` (core/lib.rs:304-329, 437-528) in exact mode (`max_batch = 1`) at 100,000 x 300 and
+    40,000 x 768: six / five layers, descents that fill the on-chip visited set, the distance log at scale.  zero and all
+    upper layers must be byte-identical to the oracle's sequential build (= the reference with one rayon thread), and
+    the work counters {n_dist, n_exp0, n_expU} equal.
+  * `Hnsw::search` (core/lib.rs:352-383) at dimensions NO compile-time geometry exists for (384, 1024: the runtime-geometry
+    walk) and real size: the oracle searches the exported graph; ids, order, counts, distance bits and work counters
+    must be identical at two ef_search values (id set / quotient set).
+
+The oracle's exact builds take minutes even with `threads = -8` (insertions strictly sequential, the independent neighbour
+updates of one insertion on 8 threads: the same bytes as `threads = 1`, pinned by tests/test_oracle_golden.py): they run
+in background threads (ctypes drops the GIL) from the moment the module's first test starts, while the GPU inserts the
+same points."""
+import concurrent.futures as cf
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+
+EXACT_CASES = [(100_000, 300), (40_000, 768)]
+
+
+def fasttext_shape(n, dim, seed):
+    """bench.py's synthetic rows: 32-d latent + 5 % noise, L2-normalised."""
+    rng = np.random.default_rng(seed)
+    z = rng.standard_normal((n, 32), dtype=np.float32)
+    a = np.random.default_rng(4242).standard_normal((32, dim), dtype=np.float32)
+    pts = z @ a
+    pts += np.float32(0.05) * rng.standard_normal((n, dim), dtype=np.float32)
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    return np.ascontiguousarray(pts, dtype=np.float32)
+
+
+@pytest.fixture(scope="module")
+def oracle_builds(oracle):
+    pool = cf.ThreadPoolExecutor(len(EXACT_CASES))
+    jobs = {}
+    for n, dim in EXACT_CASES:
+        pts = fasttext_shape(n, dim, 7 + dim)
+        jobs[(n, dim)] = (pts, pool.submit(oracle.Index.build, pts, oracle.default_config(), -8))
+    yield jobs
+    pool.shutdown(wait=True, cancel_futures=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dim", EXACT_CASES)
+def test_build_exact_gpu_large(engine_loader, oracle, oracle_builds, n, dim):
+    ida = engine_loader("gpu")
+    pts, job = oracle_builds[(n, dim)]
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder().max_batch(1))
+    zero, layers = h.into_parts()
+    st = h.build_stats()
+    oix = job.result()
+    assert len(layers) == len(oix.layers) == len(oracle.layer_sizes(n)) - 1
+    assert np.array_equal(zero, oix.zero), f"{int((zero != oix.zero).any(1).sum())} of {n} zero rows differ"
+    for l, (a, o) in enumerate(zip(layers, oix.layers)):
+        assert np.array_equal(a, o), f"layer {l + 1} differs"
+    assert (st.n_dist, st.n_exp0, st.n_expU) == (oix.build_counters.n_dist, oix.build_counters.n_exp0, oix.build_counters.n_expU)
+    assert st.n_batches == n - 1 and st.tie_overflow == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dim,nq", [(200_000, 384, 2000), (60_000, 1024, 1000), (50_000, 100, 1000)])
+def test_search_parity_runtime_geometry_at_size_gpu(engine_loader, oracle, n, dim, nq):
+    ida = engine_loader("gpu")
+    pts = fasttext_shape(n, dim, 11)
+    q = fasttext_shape(nq, dim, 12)
+    q[:32] = pts[:32]
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder())
+    zero, layers = h.into_parts()
+    assert [l.shape[0] for l in layers] == oracle.layer_sizes(n)[1:]
+    oix = oracle.Index.from_arrays(pts, zero, layers, oracle.default_config())
+    for ef in (100, 250):
+        h.set_ef_search(ef)
+        oix.set_ef_search(ef)
+        want = oix.search(q, threads=8)
+        got = h.search_batch(q, ida.Search(), counters=True)                 # wide batch: one wave per query
+        pc.check_search_result(got, want)
+        narrow = h.search_batch(q[:64], ida.Search(), counters=True)         # narrow batch: four waves per query
+        assert np.array_equal(narrow.pid, want.pid[:64]) and np.array_equal(narrow.counters, want.counters[:64])
+        assert np.array_equal(pc.bits(narrow.distance), pc.bits(want.dist[:64]))
+        assert np.all(got.count == ef) and np.all(got.distance[:, :-1] <= got.distance[:, 1:])
+        assert np.array_equal(got.pid[:32, 0], np.arange(32)) and np.all(got.distance[:32, 0] == 0)   # stored points find themselves
+    truth, _ = h.bruteforce(q[:512], 10)
+    assert pc.recall_at(got.pid[:512], truth, 10) > 0.9
