@@ -220,11 +220,13 @@ struct Knobs {
     bool tab_q16 = false;         // IDIST_TAB_FORMAT=q16: quotients wherever they apply, also where the policy would keep ids
     bool no_zero_copy = false;    // IDIST_NO_ZERO_COPY=1: narrow host-pointer batches take the general (staged) path too (test / A-B knob)
     int tune = -1;                // IDIST_TUNE=<i> (tuning builds only, -DIDIST_TUNE): i-th experimental walk variant
+    int ea = 0;                   // IDIST_EA=<k> (measurement builds only, -DIDIST_EA_PROBE): early abandon after k blocks of a 300-d row
     uint32_t quad_nq = 0xFFFFFFFFu;   // IDIST_QUAD_NQ: batches up to this many queries run four waves per query (default: two
                                       // workgroups per CU, one for 768-d rows; 0 = never)
     static Knobs from_env() {
         Knobs k;
         if (const char* e = getenv("IDIST_TUNE")) k.tune = atoi(e);
+        if (const char* e = getenv("IDIST_EA")) k.ea = atoi(e);
         if (const char* e = getenv("IDIST_LATENCY_NQ")) k.latency_nq = (uint32_t)strtoul(e, nullptr, 10);
         if (const char* e = getenv("IDIST_QUAD_NQ")) k.quad_nq = (uint32_t)std::min<unsigned long>(strtoul(e, nullptr, 10), 0xFFFFFFFEul);
         if (const char* e = getenv("IDIST_WALK")) k.classic = e[0] == 'c';
@@ -506,8 +508,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     const uint32_t a_waves_max = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)((160u * 1024u) / smem)));
     a_waves = std::min(a_waves, a_waves_max);
     uint32_t* d_zero2 = nullptr;
-    hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr;
-    hipEvent_t evA[2] = {nullptr, nullptr}, evS[2] = {nullptr, nullptr};
+    hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr, s4 = nullptr;
+    hipEvent_t evA[2] = {nullptr, nullptr}, evS[2] = {nullptr, nullptr}, evA2[2] = {nullptr, nullptr}, evC = nullptr;
     // The descents of odd and even steps run on streams of their own (pipelined schedule): step k + 1's descents depend on
     // the updates of step k - 1 only, so they may start while step k's are still draining — the tail of every launch (a
     // few hundred waves finishing their last item while the rest of the chip idles, ~6 % of a step) is filled by the next
@@ -515,13 +517,21 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // side by side.  Everything a descent launch owns is kept per parity: visited bitmaps, work-queue head, the step-A
     // outputs.  IDIST_BUILD_A_STREAMS=1: one descent stream (round 3's schedule; same graphs).
     bool two_a = !tie_spill && !(getenv("IDIST_BUILD_A_STREAMS") && getenv("IDIST_BUILD_A_STREAMS")[0] == '1');
+    // The new points' selection (step A2: matrix cores and LDS) of step k needs its descents and nothing else, the
+    // neighbour updates (steps B / B2: dependent gathers) of step k - 1 need the selection of k - 1: on streams of their
+    // own they overlap, and step A2 leaves the chain  descents(k) -> selection(k) -> updates(k) -> descents(k + 2).  What
+    // the selection hands to the updates — the inboxes (head / next / edge records), the touched list, the counters — is
+    // kept per parity for that.  IDIST_BUILD_A2_STREAM=0: selection and updates on one stream (round 3's schedule).
+    bool own_a2 = !(getenv("IDIST_BUILD_A2_STREAM") && getenv("IDIST_BUILD_A2_STREAM")[0] == '0');
     auto release = [&]() {
         hipFree(d_zero2);
         hipFree(d_ext_work);
         if (s1) hipStreamDestroy(s1);
         if (s2) hipStreamDestroy(s2);
         if (s3) hipStreamDestroy(s3);
-        for (int i = 0; i < 2; i++) { if (evA[i]) hipEventDestroy(evA[i]); if (evS[i]) hipEventDestroy(evS[i]); }
+        if (s4) hipStreamDestroy(s4);
+        for (int i = 0; i < 2; i++) { if (evA[i]) hipEventDestroy(evA[i]); if (evS[i]) hipEventDestroy(evS[i]); if (evA2[i]) hipEventDestroy(evA2[i]); }
+        if (evC) hipEventDestroy(evC);
         hipFree(d_nbr_dist); hipFree(d_row_nsel); hipFree(d_slow); hipFree(d_nbr_aux); hipFree(d_wbuf); hipFree(d_wcount); hipFree(d_dlog_log); hipFree(d_dlog_pd);
         hipFree(d_vis); hipFree(d_tie_spill); hipFree(d_edge_pid); hipFree(d_edge_dist); hipFree(d_head);
         hipFree(d_next); hipFree(d_touched); hipFree(d_small); hipFree(d_stats);
@@ -548,7 +558,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     BCHK(hipMemset(d_nbr_aux, 0, (size_t)n * IDIST_M2 * 4));
     BCHK(hipMalloc((void**)&d_row_nsel, (size_t)n * 4));
     BCHK(hipMemset(d_row_nsel, 0, (size_t)n * 4));
-    BCHK(hipMalloc((void**)&d_slow, n_touch * 4));
+    own_a2 = own_a2 && pipe;
+    const size_t nib = own_a2 ? 2 : 1;                                   // inbox sets
+    BCHK(hipMalloc((void**)&d_slow, nib * n_touch * 4));
     const size_t np = pipe ? 2 : 1;       // step-A outputs are double-buffered in the pipelined schedule
     BCHK(hipMalloc((void**)&d_wbuf, np * cap * cfg.ef_construction * 8));
     BCHK(hipMalloc((void**)&d_wcount, np * cap * 4));
@@ -561,14 +573,19 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         BCHK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
         BCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
         if (two_a) BCHK(hipStreamCreateWithFlags(&s3, hipStreamNonBlocking));
+        if (own_a2) {
+            BCHK(hipStreamCreateWithFlags(&s4, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++) BCHK(hipEventCreate(&evA2[i]));
+            BCHK(hipEventCreate(&evC));
+        }
         for (int i = 0; i < 2; i++) { BCHK(hipEventCreate(&evA[i])); BCHK(hipEventCreate(&evS[i])); }
     }
-    BCHK(hipMalloc((void**)&d_edge_pid, n_edges * 4));
-    BCHK(hipMalloc((void**)&d_edge_dist, n_edges * 4));
-    BCHK(hipMalloc((void**)&d_next, n_edges * 4));
-    BCHK(hipMalloc((void**)&d_head, (size_t)n * 4));
-    BCHK(hipMemset(d_head, 0xFF, (size_t)n * 4));
-    BCHK(hipMalloc((void**)&d_touched, n_touch * 4));
+    BCHK(hipMalloc((void**)&d_edge_pid, nib * n_edges * 4));
+    BCHK(hipMalloc((void**)&d_edge_dist, nib * n_edges * 4));
+    BCHK(hipMalloc((void**)&d_next, nib * n_edges * 4));
+    BCHK(hipMalloc((void**)&d_head, nib * (size_t)n * 4));
+    BCHK(hipMemset(d_head, 0xFF, nib * (size_t)n * 4));
+    BCHK(hipMalloc((void**)&d_touched, nib * n_touch * 4));
     BCHK(hipMalloc((void**)&d_small, 256));
     BCHK(hipMemset(d_small, 0, 256));
     BCHK(hipMalloc((void**)&d_stats, 128));
@@ -677,9 +694,19 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             const uint32_t gridA2 = std::min<uint32_t>(B, (uint32_t)ix->n_cu * 4);
             const uint32_t gridA2m = std::min<uint32_t>(B, (uint32_t)ix->n_cu * 2);
             BuildArgs aS = aA;                                             // same step-A outputs, own counters
-            aS.queue = smallS + 1;
-            aS.n_slow = smallS + 3;
+            uint32_t* const cnt = smallS + (own_a2 && par ? 8 : 0);        // this step's n_touched / queue heads / n_slow
+            aS.n_touched = cnt;
+            aS.queue = cnt + 1;
+            aS.n_slow = cnt + 3;
             aS.visited = d_vis;
+            if (own_a2 && par) {                                           // this step's inboxes
+                aS.edge_pid = d_edge_pid + n_edges; aS.edge_dist = d_edge_dist + n_edges; aS.next = d_next + n_edges;
+                aS.head = d_head + n; aS.touched = d_touched + n_touch; aS.slow = d_slow + n_touch;
+            }
+            // (carry-over of the previous step's rows: its touched list)
+            const uint32_t* const prev_touched = own_a2 ? d_touched + (par ? 0 : n_touch) : a.touched;
+            const uint32_t* const prev_cnt = own_a2 ? smallS + (par ? 0 : 8) : smallS;
+            hipStream_t sA2 = own_a2 ? s4 : sS;
             BuildArgs af = aS;
             af.efc = no_fast ? 0u : cfg.ef_construction;                  // efc = 0 makes the fast kernel defer everything
 #define LAUNCH_BUILD(NB_, RS_, TAIL_)                                                              \
@@ -707,14 +734,24 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         else { IDIST_LAUNCH(kAo, gridA, 64, smem, sA, viewA, aA); }                                \
         if (pipe) {                                                                                \
             BCHK(hipEventRecord(evA[par], sA));                                                    \
-            BCHK(hipStreamWaitEvent(s2, evA[par], 0));                                             \
-            IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s2, zbuf[par ^ 1], zbuf[par], a.touched, smallS, prev_start, prev_count); \
-            BCHK(hipMemsetAsync(smallS, 0, 32, s2));                                               \
+            BCHK(hipStreamWaitEvent(sA2, evA[par], 0));                                            \
+            /* this step's inbox set is the one step k - 1's carry-over reads its touched list from (recorded below) */ \
+            if (own_a2 && k > 1) BCHK(hipStreamWaitEvent(s4, evC, 0));                             \
+            if (!own_a2) {                                                                         \
+                IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s2, zbuf[par ^ 1], zbuf[par], prev_touched, prev_cnt, prev_start, prev_count); \
+            }                                                                                      \
+            BCHK(hipMemsetAsync(cnt, 0, 32, sA2));                                                 \
         }                                                                                          \
         if (ext) {                                                                                 \
         } else if (cfg.has_heuristic) {                                                            \
-            if (a2_mfma) { IDIST_LAUNCH(kA2m, gridA2m, 256, smemA2m, sS, viewS, aS); }             \
-            else { IDIST_LAUNCH(kA2, gridA2, 64, smemA2, sS, viewS, aS); }                         \
+            if (a2_mfma) { IDIST_LAUNCH(kA2m, gridA2m, 256, smemA2m, sA2, viewS, aS); }            \
+            else { IDIST_LAUNCH(kA2, gridA2, 64, smemA2, sA2, viewS, aS); }                        \
+            if (own_a2) {                                                                          \
+                BCHK(hipEventRecord(evA2[par], s4));                                               \
+                BCHK(hipStreamWaitEvent(s2, evA2[par], 0));                                        \
+                IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s2, zbuf[par ^ 1], zbuf[par], prev_touched, prev_cnt, prev_start, prev_count); \
+                BCHK(hipEventRecord(evC, s2));                                                     \
+            }                                                                                      \
             IDIST_LAUNCH(kF, gridB, 64, smemF, sS, viewS, af);                                     \
             IDIST_LAUNCH(kB, gridS, 64, smemB, sS, viewS, aS);                                     \
         } else {                                                                                   \
@@ -747,7 +784,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             // self-check: carry the last step over as well; now the two copies must agree on every row, or some
             // step's carry-over missed a row
             const int par = (int)(n_batches & 1u);
-            IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s1, zbuf[par], zbuf[par ^ 1], a.touched, smallS, prev_start, prev_count);
+            IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s1, zbuf[par], zbuf[par ^ 1], own_a2 && par ? d_touched + n_touch : a.touched,
+                         smallS + (own_a2 && par ? 8 : 0), prev_start, prev_count);
             BCHK(hipMemsetAsync(d_small + 40, 0, 4, s1));
             IDIST_LAUNCH(count_row_mismatch_kernel, 1024, 256, 0, s1, zbuf[0], zbuf[1], n, d_small + 40);
             uint32_t bad = 0;
@@ -981,6 +1019,22 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         }                                                                                          \
     }
+#ifdef IDIST_EA_PROBE
+    // measurement build: wide 300-d batches on the id set with partial-distance early abandon after k blocks (dist_rounds_inflight)
+    if (on_chip && !quad && !q16 && !classic && ctx->knobs.ea > 0 && ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) {
+#define EA_CASE(K_)                                                                                   \
+    case K_: {                                                                                        \
+        auto kS = search_kernel<9, 1, 1, walk_with_ea(walk_code(kWalkOverlap, 0, false, 1, true), K_)>; \
+        IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                            \
+        break;                                                                                        \
+    }
+        switch (ctx->knobs.ea) {
+            EA_CASE(4) EA_CASE(5) EA_CASE(6) EA_CASE(7)
+            default: return fail(IDIST_ERR_INVALID_ARG, "IDIST_EA=%d: 4..7", ctx->knobs.ea);
+        }
+#undef EA_CASE
+    } else
+#endif
 #ifdef IDIST_TUNE
     // tuning build: full 300-d batches through one of the experimental variants of the walk
     if (on_chip && ctx->knobs.tune >= 0 && ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) {

@@ -153,10 +153,96 @@ __device__ __forceinline__ float fold_chains(float acc, bool has_tail, float tq,
 // mid(): work of the caller that does not depend on the distances — it runs once, after the first batch of row loads
 // has been issued and before anything waits for them (the walk inserts the new ids into its visited set there).
 struct NoMid { __device__ __forceinline__ void operator()() const {} };
-template <int NB, int RS, int TAIL, int RIF, bool QREGS = true, int RSTEP = 8, class Mid = NoMid>
+constexpr uint32_t kAbandoned = 0xFFFFFFFFu;   // act_dist of a row given up early: above every canonical distance pattern
+// EAK > 0 (measurement builds, `make probe`): partial-distance early abandon.  Only the first EAK blocks of every row are
+// requested at first; the canonical fold of the partial chains is a LOWER bound of the row's canonical distance (every
+// term is >= 0 and round-to-nearest is monotone, so each chain's prefix <= the chain and each add of the fold keeps the
+// order), and a row whose bound already exceeds thr_bits — the furthest distance of a full `nearest` when the expansion
+// began; `nearest` only improves during it — can only be rejected by `push` (core/lib.rs:712-714): its remaining blocks are
+// never fetched and it is reported as kAbandoned.  Same decisions, same results, same n_dist; fewer bytes, but a second,
+// dependent load stage for the rows that stay.
+template <int NB, int RS, int TAIL, int RIF, bool QREGS = true, int RSTEP = 8, class Mid = NoMid, int EAK = 0>
 __device__ __forceinline__ void dist_rounds_inflight(const IndexView& ix, const VecView qv, const uint32_t* act_pid,
-                                                     uint32_t* act_dist, int na, int first = 0, Mid mid = Mid()) {
+                                                     uint32_t* act_dist, int na, int first = 0, Mid mid = Mid(),
+                                                     uint32_t thr_bits = 0xFFFFFFFFu) {
     static_assert(NB >= 0 && RS >= 0 && TAIL >= 0 && RIF >= 1, "compile-time layout only");
+    if constexpr (EAK > 0 && EAK < NB) {
+        const int lane = lane_id();
+        const int g = lane >> 3, j = lane & 7;
+        constexpr int RSA = RS > 0 ? RS : 1;
+        float4 qf[NB];                                                    // the lane's query fragment (one wave per SIMD: registers to spare)
+#pragma unroll
+        for (int u = 0; u < NB; u++) qf[u] = *reinterpret_cast<const float4*>(qv.blk + u * qv.bstride + j * 4);
+        for (int base = first; base < na; base += RSTEP * RIF) {
+            float4 p[RIF][NB];
+            float pr[RIF][RSA], pt[RIF];
+            const float* row[RIF];
+            bool on[RIF], alive[RIF];
+#pragma unroll
+            for (int r = 0; r < RIF; r++) {
+                const int k = base + RSTEP * r + g;
+                on[r] = k < na;
+                row[r] = ix.points + (size_t)act_pid[on[r] ? k : first] * ix.stride;
+                if (on[r]) {
+#pragma unroll
+                    for (int u = 0; u < EAK; u++) p[r][u] = ldg_row4(row[r] + u * 32 + j * 4);
+                }
+            }
+            if (base == first) mid();
+            float acc[RIF];
+#pragma unroll
+            for (int r = 0; r < RIF; r++) {
+                acc[r] = 0.0f;
+                pt[r] = 0.0f;
+                alive[r] = false;
+                if (on[r]) {
+#pragma unroll
+                    for (int u = 0; u < EAK; u++) {
+                        const float4 w = qf[u];
+                        float d;
+                        d = w.x - p[r][u].x; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                        d = w.y - p[r][u].y; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                        d = w.z - p[r][u].z; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                        d = w.w - p[r][u].w; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                    }
+                }
+                float lb = fold_chains(acc[r], false, 0.0f, 0.0f);        // lanes j < 4 of the group hold the bound
+                const float lb_hi = dpp_move<0x114>(lb);                  // row_shr:4 — lanes j >= 4 take it from lane j - 4
+                lb = j < 4 ? lb : lb_hi;
+                alive[r] = on[r] && !(canon_bits(lb, ix.metric) > thr_bits);
+                if (alive[r]) {                                           // the rest of the row, requested as soon as its bound is known
+#pragma unroll
+                    for (int u = EAK; u < NB; u++) p[r][u] = ldg_row4(row[r] + u * 32 + j * 4);
+#pragma unroll
+                    for (int c = 0; c < RS; c++) pr[r][c] = row[r][NB * 32 + c * 8 + j];
+                    if (TAIL) pt[r] = row[r][NB * 32 + RS * 8 + (j & 3)];
+                }
+            }
+            const float qt = TAIL ? qv.rem[RS * 8 + (j & 3)] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < RIF; r++) {
+                if (alive[r]) {
+#pragma unroll
+                    for (int u = EAK; u < NB; u++) {
+                        const float4 w = qf[u];
+                        float d;
+                        d = w.x - p[r][u].x; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                        d = w.y - p[r][u].y; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                        d = w.z - p[r][u].z; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                        d = w.w - p[r][u].w; acc[r] = __builtin_fmaf(d, d, acc[r]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < RS; c++) {
+                        const float d = qv.rem[c * 8 + j] - pr[r][c];
+                        acc[r] = __builtin_fmaf(d, d, acc[r]);
+                    }
+                }
+                const float res = fold_chains(acc[r], TAIL && alive[r], qt, pt[r]);
+                if (on[r] && j == 0) act_dist[base + RSTEP * r + g] = alive[r] ? canon_bits(res, ix.metric) : kAbandoned;
+            }
+        }
+        return;
+    }
     const int lane = lane_id();
     const int g = lane >> 3, j = lane & 7;
     constexpr int NBA = NB > 0 ? NB : 1, RSA = RS > 0 ? RS : 1;
@@ -427,6 +513,9 @@ constexpr int walk_mode(int code) { return code & 3; }
 constexpr int walk_rif(int code) { return (code >> 4) & 15; }
 constexpr bool walk_q_lds(int code) { return ((code >> 8) & 1) != 0; }
 constexpr int walk_waves(int code) { return (code >> 12) & 7; }
+// bits 15-18 (measurement builds only): blocks of a row fetched before the early-abandon test, 0 = off
+constexpr int walk_ea(int code) { return (code >> 15) & 15; }
+constexpr int walk_with_ea(int code, int blocks) { return code | (blocks << 15); }
 #ifndef IDIST_RIF9
 #define IDIST_RIF9 4
 #endif
@@ -452,8 +541,13 @@ template <int WALK> constexpr int rt_rounds() { return walk_waves(WALK) == 1 ? 4
 template <int WALK> constexpr int rt_blocks() { return walk_waves(WALK) == 1 ? 8 : 4; }
 template <int NB, int RS, int TAIL, int WALK, class Mid = NoMid>
 __device__ __forceinline__ void dist_rounds_walk(const IndexView& ix, const float* q, const uint32_t* act_pid,
-                                                 uint32_t* act_dist, int na, Mid mid = Mid()) {
+                                                 uint32_t* act_dist, int na, Mid mid = Mid(), uint32_t thr_bits = 0xFFFFFFFFu) {
     constexpr int RIF = rounds_in_flight<NB, WALK>();
+    if constexpr (NB >= 0 && walk_ea(WALK) > 0) {
+        if (na <= 0) mid();
+        dist_rounds_inflight<NB, RS, TAIL, RIF, !walk_q_lds(WALK), 8, Mid, walk_ea(WALK)>(ix, natural_view(q, NB), act_pid, act_dist, na, 0, mid, thr_bits);
+        return;
+    }
     if constexpr (NB < 0 && walk_mode(WALK) != kWalkClassic) {
         if (na <= 0) mid();
         dist_rounds_inflight_rt<rt_blocks<WALK>(), rt_rounds<WALK>()>(ix, natural_view(q, (int)ix.nb), act_pid, act_dist, na, 0, mid);
@@ -1433,8 +1527,11 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 wave_sync();
                 [[maybe_unused]] const uint32_t tk1 = IDIST_TICK();
                 auto mid = [&]() { if (defer && fresh) tab_idx = tab_insert(vis, nb_pid); };
+                // early abandon (measurement builds): the furthest distance of a full `nearest` as this expansion begins
+                [[maybe_unused]] uint32_t thr_bits = 0xFFFFFFFFu;
+                if constexpr (walk_ea(LAT) > 0) { if (st.plen >= st.ef && !dlog.log) thr_bits = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32); }
                 if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, na, mid);
-                else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na, mid);     // :709-710
+                else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na, mid, thr_bits);     // :709-710
                 wave_sync();
 #ifdef IDIST_PHASES
                 const uint32_t tk2 = IDIST_TICK();

@@ -1156,17 +1156,19 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
                 pb[3] += (uint32_t)n0;
                 pb[4] += (uint32_t)__popcll(__ballot(lane < ns0 && dv == kDlogMiss && X[lane] < a.start && X[lane] + a.count >= a.start));
                 pb[5] += (uint32_t)__popcll(__ballot(lane < ns0 && dv == kDlogMiss && X[lane] >= a.start));
-                pb[6] += (uint32_t)k_new;
+                pb[6] += (uint32_t)ai;
 #endif
                 if (lane < ns0 && dv == kDlogMiss) {
                     const int at = __popcll(mm & ((1ull << lane) - 1ull));
                     act_x[at] = (uint32_t)lane;
                 }
-                if (lane < k_new) act_x[n0 + lane] = (uint32_t)(ns0 + lane);
-                nmiss = n0 + k_new;
+                // ... and the new points nearer to `pid` than this one: the replay reads d(a, b) of two new points from the row
+                // of the LATER one (the one further from `pid`) only, and never the self column — so point ai needs the
+                // columns of points 0 .. ai - 1, and the nearest new point (ai = 0) none at all
+                if (lane < ai) act_x[n0 + lane] = (uint32_t)(ns0 + lane);
+                nmiss = n0 + ai;
                 wave_sync();
-                if (nmiss > (k_new > 1 ? 0 : 1) || n0 > 0) {
-                    // (with a single new point and no miss nothing is needed: the self column is never read)
+                if (nmiss > 0) {
                     for (int i = lane; i < nmiss; i += 64) act_p[i] = X[act_x[i]];
                     const float* prow = ix.points + (size_t)a_pid * ix.stride;
                     for (uint32_t o = lane * 4; o < ix.stride; o += 256)
