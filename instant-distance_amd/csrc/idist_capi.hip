@@ -219,17 +219,15 @@ struct Knobs {
                                   // 16-bit quotients (8 per bucket, single ids overflow) (test / A-B knob)
     bool tab_q16 = false;         // IDIST_TAB_FORMAT=q16: quotients wherever they apply, also where the policy would keep ids
     bool no_zero_copy = false;    // IDIST_NO_ZERO_COPY=1: narrow host-pointer batches take the general (staged) path too (test / A-B knob)
-    int tune = -1;                // IDIST_TUNE=<i> (tuning builds only, -DIDIST_TUNE): i-th experimental walk variant
     int ea = 0;                   // IDIST_EA=<k> (measurement builds only, -DIDIST_EA_PROBE): early abandon after k blocks of a 300-d row
     uint32_t quad_nq = 0xFFFFFFFFu;   // IDIST_QUAD_NQ: batches up to this many queries run four waves per query (default: two
                                       // workgroups per CU, one for 768-d rows; 0 = never)
     static Knobs from_env() {
         Knobs k;
-        if (const char* e = getenv("IDIST_TUNE")) k.tune = atoi(e);
         if (const char* e = getenv("IDIST_EA")) k.ea = atoi(e);
         if (const char* e = getenv("IDIST_LATENCY_NQ")) k.latency_nq = (uint32_t)strtoul(e, nullptr, 10);
         if (const char* e = getenv("IDIST_QUAD_NQ")) k.quad_nq = (uint32_t)std::min<unsigned long>(strtoul(e, nullptr, 10), 0xFFFFFFFEul);
-        if (const char* e = getenv("IDIST_WALK")) k.classic = e[0] == 'c';
+        if (const char* e = getenv("IDIST_WALK")) k.classic = e[0] == 'c';      // (honoured by the test build only, see variants_check)
         if (const char* e = getenv("IDIST_BLOOM")) k.bloom = e[0] != '0';
         if (const char* e = getenv("IDIST_VISITED")) { k.vis_bitmap = e[0] == 'b'; k.vis_onchip = e[0] == 'o'; }
         if (const char* e = getenv("IDIST_NO_ZERO_COPY")) k.no_zero_copy = e[0] != '0';
@@ -391,6 +389,16 @@ constexpr size_t kOnChipLdsPerWave = 40 * 1024;
 thread_local uint32_t g_tie_cap_msg = kTieCap;
 uint32_t tie_capacity(const idist_config& cfg) { return g_tie_cap_msg = cfg.tie_capacity ? cfg.tie_capacity : (uint32_t)kTieCap; }
 
+// IDIST_WALK=classic names walks that only the test build holds (libidist_variants.so): say so instead of running
+// something else under that name
+idist_status variants_check(bool classic) {
+#ifndef IDIST_VARIANTS
+    if (classic) return fail(IDIST_ERR_UNSUPPORTED, "IDIST_WALK=classic selects a test-only variant of the walk: load libidist_variants.so (make -C instant-distance_amd/csrc variants)");
+#endif
+    (void)classic;
+    return IDIST_OK;
+}
+
 idist_status device_status_to_code(uint32_t st, int32_t tie_policy) {
     if (st & kStBadRow) return fail(IDIST_ERR_BAD_GRAPH, "device met an adjacency id >= n");
     if ((st & kStTieOverflow) && tie_policy == IDIST_TIES_STRICT)
@@ -421,6 +429,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     if (tie_spill) slots = std::min<uint32_t>(slots, (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)n * 8)));
     const VisGeom vg = vis_geometry(n);
     const Knobs knobs = Knobs::from_env();
+    CHK(variants_check(knobs.classic));
     const uint32_t tie_cap = tie_capacity(cfg);
     const uint32_t wcap = cfg.ef_construction + 64 + tie_cap + 64;
     // The descents' on-chip visited set.  Quotient form (16-bit entries, idist_device.hpp q16_*) where n allows it: 16 KB hold
@@ -510,19 +519,19 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     uint32_t* d_zero2 = nullptr;
     hipStream_t s1 = nullptr, s2 = nullptr, s3 = nullptr, s4 = nullptr;
     hipEvent_t evA[2] = {nullptr, nullptr}, evS[2] = {nullptr, nullptr}, evA2[2] = {nullptr, nullptr}, evC = nullptr;
-    // The descents of odd and even steps run on streams of their own (pipelined schedule): step k + 1's descents depend on
-    // the updates of step k - 1 only, so they may start while step k's are still draining — the tail of every launch (a
-    // few hundred waves finishing their last item while the rest of the chip idles, ~6 % of a step) is filled by the next
-    // step's first items, and in the growth phase of a layer (steps narrower than the chip) two steps' descents simply run
-    // side by side.  Everything a descent launch owns is kept per parity: visited bitmaps, work-queue head, the step-A
-    // outputs.  IDIST_BUILD_A_STREAMS=1: one descent stream (round 3's schedule; same graphs).
-    bool two_a = !tie_spill && !(getenv("IDIST_BUILD_A_STREAMS") && getenv("IDIST_BUILD_A_STREAMS")[0] == '1');
-    // The new points' selection (step A2: matrix cores and LDS) of step k needs its descents and nothing else, the
-    // neighbour updates (steps B / B2: dependent gathers) of step k - 1 need the selection of k - 1: on streams of their
-    // own they overlap, and step A2 leaves the chain  descents(k) -> selection(k) -> updates(k) -> descents(k + 2).  What
-    // the selection hands to the updates — the inboxes (head / next / edge records), the touched list, the counters — is
-    // kept per parity for that.  IDIST_BUILD_A2_STREAM=0: selection and updates on one stream (round 3's schedule).
-    bool own_a2 = !(getenv("IDIST_BUILD_A2_STREAM") && getenv("IDIST_BUILD_A2_STREAM")[0] == '0');
+    // Narrow steps (the growth phase of every layer: fewer insertions than the chip has room for) are bound by the latency of
+    // one descent plus five dependent launches, not by throughput, so there the two parity chains of the pipeline
+    //     descents(k) -> selection(k) -> updates(k) -> descents(k + 2)
+    // get streams of their own: the descents of odd steps (s3) run beside those of even steps (s1), and the new points'
+    // selection (s4: matrix cores and LDS) beside the previous step's neighbour updates (s2: dependent gathers).  Everything
+    // a launch owns is kept per parity for that — visited bitmaps, work-queue heads, step-A outputs, the inboxes the selection
+    // hands to the updates.  Wide steps saturate the memory system whatever the layout (profiles/probe_r04_build_schedule:
+    // the extra overlap costs 2 %), so they keep one descent stream and one update stream.
+    // IDIST_BUILD_STREAMS=off | narrow (default) | all.
+    int stream_mode = 1;
+    if (const char* e = getenv("IDIST_BUILD_STREAMS")) stream_mode = e[0] == 'o' ? 0 : (e[0] == 'a' ? 2 : 1);
+    bool two_a = !tie_spill && stream_mode != 0;
+    bool own_a2 = stream_mode != 0;
     auto release = [&]() {
         hipFree(d_zero2);
         hipFree(d_ext_work);
@@ -666,7 +675,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             a.count = B;
             const uint64_t k = n_batches + 1;                              // step number, 1-based
             const int par = (int)(k & 1u);
-            hipStream_t sA = pipe ? (two_a && par ? s3 : s1) : stream, sS = pipe ? s2 : stream;
+            const bool alt = stream_mode == 2 || (stream_mode == 1 && B <= quad_B);   // this step on the extra streams
+            hipStream_t sA = pipe ? (two_a && alt && par ? s3 : s1) : stream, sS = pipe ? s2 : stream;
             IndexView viewA = view, viewS = view;
             BuildArgs aA = a;
             if (pipe) {
@@ -706,14 +716,24 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             // (carry-over of the previous step's rows: its touched list)
             const uint32_t* const prev_touched = own_a2 ? d_touched + (par ? 0 : n_touch) : a.touched;
             const uint32_t* const prev_cnt = own_a2 ? smallS + (par ? 0 : 8) : smallS;
-            hipStream_t sA2 = own_a2 ? s4 : sS;
+            hipStream_t sA2 = own_a2 && alt ? s4 : sS;
             BuildArgs af = aS;
             af.efc = no_fast ? 0u : cfg.ef_construction;                  // efc = 0 makes the fast kernel defer everything
+#ifdef IDIST_VARIANTS
+#define IDIST_VARIANT_BUILD(NB_, RS_, TAIL_)                                                                          \
+    else if (classic && tab16) {                                                                                      \
+        auto kA16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true, false, true)>;    \
+        IDIST_LAUNCH(kA16, gridA, 64, smem, sA, viewA, aA);                                                           \
+    } else if (classic) {                                                                                             \
+        auto kA = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>;                   \
+        IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA);                                                             \
+    }
+#else
+#define IDIST_VARIANT_BUILD(NB_, RS_, TAIL_)
+#endif
 #define LAUNCH_BUILD(NB_, RS_, TAIL_)                                                              \
     {                                                                                              \
-        auto kA = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>; \
         auto kAo = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true)>; \
-        auto kA16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true, false, true)>; \
         auto kAo16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
         /* two descent waves per SIMD: 256 registers each, fewer rounds in flight per wave, more waves */ \
         /* narrow steps (the growth phase of a layer, max_batch = 1): four waves per insertion, like narrow search batches */ \
@@ -726,19 +746,19 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         auto kX = build_extend_kernel<NB_, RS_, TAIL_>;                                            \
         auto kA2m = build_select_mfma_kernel<NB_, RS_, TAIL_>;                                     \
         if (ext) { IDIST_LAUNCH(kX, 1, 64, smemX, sA, viewA, aA, d_ext_work, ext_cap); }           \
-        else if (classic && tab16) { IDIST_LAUNCH(kA16, gridA, 64, smem, sA, viewA, aA); }         \
+        IDIST_VARIANT_BUILD(NB_, RS_, TAIL_)                                                       \
         else if (tab16 && a_quad && B <= quad_B) { IDIST_LAUNCH(kAq16, std::min(B, slots), 256, smem, sA, viewA, aA); } \
         else if (tab16 && a_regs256) { IDIST_LAUNCH(kAo16w2, gridA, 64, smem, sA, viewA, aA); }    \
         else if (tab16) { IDIST_LAUNCH(kAo16, gridA, 64, smem, sA, viewA, aA); }                   \
-        else if (classic) { IDIST_LAUNCH(kA, gridA, 64, smem, sA, viewA, aA); }                    \
         else { IDIST_LAUNCH(kAo, gridA, 64, smem, sA, viewA, aA); }                                \
         if (pipe) {                                                                                \
             BCHK(hipEventRecord(evA[par], sA));                                                    \
             BCHK(hipStreamWaitEvent(sA2, evA[par], 0));                                            \
-            /* this step's inbox set is the one step k - 1's carry-over reads its touched list from (recorded below) */ \
-            if (own_a2 && k > 1) BCHK(hipStreamWaitEvent(s4, evC, 0));                             \
-            if (!own_a2) {                                                                         \
+            /* this step's inbox set is the one step k - 1's carry-over reads its touched list from (evC, recorded below) */ \
+            if (sA2 != s2 && k > 1) BCHK(hipStreamWaitEvent(sA2, evC, 0));                         \
+            if (sA2 == s2) {                                                                       \
                 IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s2, zbuf[par ^ 1], zbuf[par], prev_touched, prev_cnt, prev_start, prev_count); \
+                if (own_a2) BCHK(hipEventRecord(evC, s2));                                         \
             }                                                                                      \
             BCHK(hipMemsetAsync(cnt, 0, 32, sA2));                                                 \
         }                                                                                          \
@@ -746,7 +766,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         } else if (cfg.has_heuristic) {                                                            \
             if (a2_mfma) { IDIST_LAUNCH(kA2m, gridA2m, 256, smemA2m, sA2, viewS, aS); }            \
             else { IDIST_LAUNCH(kA2, gridA2, 64, smemA2, sA2, viewS, aS); }                        \
-            if (own_a2) {                                                                          \
+            if (pipe && sA2 != s2) {                                                               \
                 BCHK(hipEventRecord(evA2[par], s4));                                               \
                 BCHK(hipStreamWaitEvent(s2, evA2[par], 0));                                        \
                 IDIST_LAUNCH(copy_rows_kernel, 1024, 64, 0, s2, zbuf[par ^ 1], zbuf[par], prev_touched, prev_cnt, prev_start, prev_count); \
@@ -907,6 +927,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
                            uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream,
                            uint32_t* status_host = nullptr, uint32_t* grid_out = nullptr, uint32_t* done_host = nullptr, uint32_t done_seq = 0) {
     const uint32_t ef = ix->cfg.ef_search;
+    CHK(variants_check(ctx->knobs.classic));
     SearchArgs a{};
     a.queries = d_q;
     a.nq = nq;
@@ -943,9 +964,6 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const bool ids_suffice = 53u * ef + 600u <= (7u << tab_log2) / 8u;
     const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits) && (ctx->knobs.tab_q16 || ctx->knobs.tab_log2 || !ids_suffice);
     uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (on_chip ? 4u : 16u));   // quad: two workgroups per CU where registers allow
-#ifdef IDIST_TUNE
-    if (const char* e = getenv("IDIST_WAVES_PER_CU")) resident = (uint32_t)ix->n_cu * (uint32_t)std::max(1, atoi(e));   // tuning builds only
-#endif
     if (ctx->tie_spill) {
         // one bag of n keys per slot (a walk can hold every point as a tie at most once); the slots that fit 1 GiB
         const uint32_t fit = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)std::max(ix->n, 1u) * 8));
@@ -988,6 +1006,30 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     if (grid_out) *grid_out = grid;
     const uint32_t slot = (uint32_t)(ctx->n_launch % IDIST_EVENT_RING);
     if (ctx->knobs.events) HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
+// The `classic` walks (one distance round in flight, no adjacency prefetch) are selected by no policy: they exist as
+// independent implementations of the same decisions for the parity tests and are compiled into the TEST build only
+// (`make variants` -> libidist_variants.so, -DIDIST_VARIANTS; the CPU emulator build defines it too).
+#ifdef IDIST_VARIANTS
+#define IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_)                                                    \
+    else if (on_chip && classic && q16) {                                                                   \
+        auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true, false, true)>;  \
+        IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                                  \
+    }
+#define IDIST_VARIANT_SEARCH_ONCHIP_IDS(NB_, RS_, TAIL_)                                                    \
+    else if (on_chip && classic) {                                                                          \
+        auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>;               \
+        IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                                  \
+    }
+#define IDIST_VARIANT_SEARCH_BITMAP(NB_, RS_, TAIL_)                                                        \
+    else if (classic) {                                                                                     \
+        auto kS = search_kernel<NB_, RS_, TAIL_, kWalkClassic>;                                             \
+        IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                                  \
+    }
+#else
+#define IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_)
+#define IDIST_VARIANT_SEARCH_ONCHIP_IDS(NB_, RS_, TAIL_)
+#define IDIST_VARIANT_SEARCH_BITMAP(NB_, RS_, TAIL_)
+#endif
 #define LAUNCH_SEARCH(NB_, RS_, TAIL_)                                                             \
     {                                                                                              \
         if (quad && q16) {                                                                         \
@@ -996,25 +1038,16 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
         } else if (quad) {                                                                         \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, true)>; \
             IDIST_LAUNCH(kS, grid, 256, smem, stream, view, a);                                    \
-        } else if (on_chip && classic && q16) {                                                    \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true, false, true)>; \
-            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
-        } else if (on_chip && q16) {                                                               \
+        } IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_) else if (on_chip && q16) {              \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
-        } else if (on_chip && classic) {                                                           \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>;  \
-            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
-        } else if (on_chip) {                                                                      \
+        } IDIST_VARIANT_SEARCH_ONCHIP_IDS(NB_, RS_, TAIL_) else if (on_chip) {                     \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true)>;  \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } else if (lat) {                                                                          \
             auto kS = search_kernel<NB_, RS_, TAIL_, kWalkLatency>;                                \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
-        } else if (classic) {                                                                      \
-            auto kS = search_kernel<NB_, RS_, TAIL_, kWalkClassic>;                                \
-            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
-        } else {                                                                                   \
+        } IDIST_VARIANT_SEARCH_BITMAP(NB_, RS_, TAIL_) else {                                      \
             auto kS = search_kernel<NB_, RS_, TAIL_, kWalkOverlap>;                                \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         }                                                                                          \
@@ -1033,37 +1066,6 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
             default: return fail(IDIST_ERR_INVALID_ARG, "IDIST_EA=%d: 4..7", ctx->knobs.ea);
         }
 #undef EA_CASE
-    } else
-#endif
-#ifdef IDIST_TUNE
-    // tuning build: full 300-d batches through one of the experimental variants of the walk
-    if (on_chip && ctx->knobs.tune >= 0 && ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) {
-#define TUNE_CASE(I_, CODE_)                                              \
-    case I_: {                                                            \
-        auto kS = search_kernel<9, 1, 1, CODE_>;                          \
-        IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                \
-        break;                                                            \
-    }
-        switch (ctx->knobs.tune) {
-            TUNE_CASE(0, walk_code(kWalkOverlap, 0, false, 1, true))    // = production (rif 4, query fragment in registers)
-            TUNE_CASE(1, walk_code(kWalkOverlap, 3, false, 1, true))
-            TUNE_CASE(2, walk_code(kWalkOverlap, 6, false, 1, true))
-            TUNE_CASE(3, walk_code(kWalkOverlap, 8, false, 1, true))
-            TUNE_CASE(4, walk_code(kWalkOverlap, 4, true, 1, true))
-            TUNE_CASE(5, walk_code(kWalkOverlap, 6, true, 1, true))
-            TUNE_CASE(6, walk_code(kWalkOverlap, 8, true, 1, true))
-            TUNE_CASE(7, walk_code(kWalkOverlap, 2, false, 1, true))
-            TUNE_CASE(8, walk_code(kWalkOverlap, 4, false, 0, true))
-            TUNE_CASE(9, walk_code(kWalkOverlap, 5, false, 1, true))
-            // quotient set (needs q16 = true, i.e. no IDIST_TAB_FORMAT=ids): one / two waves per SIMD (512 / 256 registers)
-            TUNE_CASE(10, walk_code(kWalkOverlap, 4, false, 1, true, false, true))
-            TUNE_CASE(11, walk_code(kWalkOverlap, 4, false, 2, true, false, true))
-            TUNE_CASE(12, walk_code(kWalkOverlap, 3, false, 2, true, false, true))
-            TUNE_CASE(13, walk_code(kWalkOverlap, 2, false, 2, true, false, true))
-            TUNE_CASE(14, walk_code(kWalkOverlap, 4, true, 2, true, false, true))
-            default: return fail(IDIST_ERR_INVALID_ARG, "IDIST_TUNE=%d: no such variant", ctx->knobs.tune);
-        }
-#undef TUNE_CASE
     } else
 #endif
     IDIST_DISPATCH(ix->L, LAUNCH_SEARCH);

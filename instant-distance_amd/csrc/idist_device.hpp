@@ -536,8 +536,8 @@ constexpr int rounds_in_flight() {
 }
 // register tile of the runtime geometry (dist_rounds_inflight_rt) by the kernel's register budget: one fat wave per SIMD
 // (512 registers) keeps 2 x 4 rounds x 8 blocks = 256 data registers = 64 KB on the wire; two waves per SIMD (256
-// registers: the build's descents) 2 x 3 x 4 = 96; the many-small-waves bitmap walks 2 x 2 x 4 = 64
-template <int WALK> constexpr int rt_rounds() { return walk_waves(WALK) == 1 ? 4 : (walk_waves(WALK) == 2 ? 3 : 2); }
+// registers: the build's descents) 2 x 3 x 4 = 96; the many-small-waves bitmap walks (16 per CU: 128 registers each) 2 x 1 x 4 = 32
+template <int WALK> constexpr int rt_rounds() { return walk_waves(WALK) == 1 ? 4 : (walk_waves(WALK) == 2 ? 3 : 1); }
 template <int WALK> constexpr int rt_blocks() { return walk_waves(WALK) == 1 ? 8 : 4; }
 template <int NB, int RS, int TAIL, int WALK, class Mid = NoMid>
 __device__ __forceinline__ void dist_rounds_walk(const IndexView& ix, const float* q, const uint32_t* act_pid,
@@ -1223,16 +1223,7 @@ __device__ __forceinline__ uint32_t dlog_find_q16(const uint32_t* PD, uint32_t u
 
 struct Counters {
     uint32_t n_dist, n_exp0, n_expU;
-#ifdef IDIST_PHASES
-    // instrumented build (make phases): 10-ns ticks of one walk spent before / in / after the distance passes
-    uint32_t t_pre = 0, t_dist = 0, t_post = 0;
-#endif
 };
-#ifdef IDIST_PHASES
-#define IDIST_TICK() ((uint32_t)wall_clock64())
-#else
-#define IDIST_TICK() 0u
-#endif
 
 // ---------------------------------------------------------------------------
 // Four waves per walk (narrow batches: Hnsw::search is one query per call, core/lib.rs:352-356).  A single wave
@@ -1409,8 +1400,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     constexpr bool OVL = walk_mode(LAT) != kWalkClassic && !walk_vis_lds(LAT);
     uint32_t pf_pid = kInvalid, pf_row = kInvalid;
     for (;;) {
-        [[maybe_unused]] const uint32_t tk0 = IDIST_TICK();
-        [[maybe_unused]] bool tk_on = false;
         int ci = w_pop(st);                               // :599-604
         if (ci < 0 && st.spill_n && w_refill_ties(st)) ci = w_pop(st);   // live ties that did not fit the LDS region
         if (ci < 0) break;
@@ -1435,7 +1424,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         const uint64_t inval = __ballot(nb_pid == kInvalid);
         const int nvalid = inval ? __builtin_ctzll(inval) : 64;
         const bool is_nb = lane < nvalid;
-        [[maybe_unused]] const uint32_t tkA = IDIST_TICK();       // pop, peek and the adjacency row are in
 
         if constexpr (walk_vis16(LAT)) {
             // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40, on the quotient set: one LDS round trip tells
@@ -1458,7 +1446,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             uint32_t my_d = 0;
             const uint64_t sm = __ballot(sure);
             wave_sync();
-            [[maybe_unused]] const uint32_t tk1 = IDIST_TICK();
             if (sm) {
                 const int my = __popcll(sm & ((1ull << lane) - 1ull));
                 if (sure) act_pid[my] = nb_pid;                                         // keeps slot order
@@ -1490,13 +1477,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             const bool fresh = sure || late;
             const int na = __popcll(sm) + __popcll(lm);
             if (na) {
-#ifdef IDIST_PHASES
-                const uint32_t tk2 = IDIST_TICK();
-                ctr.t_pre += tk1 - tk0;
-                ctr.t_dist += tk2 - tk1;
-                ctr.t_post -= tk2;
-                tk_on = true;
-#endif
                 ctr.n_dist += (uint32_t)na;
                 uint64_t key = kMaxKey;
                 if (fresh) key = ((uint64_t)my_d << 32) | nb_pid;
@@ -1525,7 +1505,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 const int my = __popcll(fm & ((1ull << lane) - 1ull));
                 if (fresh) act_pid[my] = nb_pid;                                        // keeps slot order
                 wave_sync();
-                [[maybe_unused]] const uint32_t tk1 = IDIST_TICK();
                 auto mid = [&]() { if (defer && fresh) tab_idx = tab_insert(vis, nb_pid); };
                 // early abandon (measurement builds): the furthest distance of a full `nearest` as this expansion begins
                 [[maybe_unused]] uint32_t thr_bits = 0xFFFFFFFFu;
@@ -1533,27 +1512,11 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, na, mid);
                 else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na, mid, thr_bits);     // :709-710
                 wave_sync();
-#ifdef IDIST_PHASES
-                const uint32_t tk2 = IDIST_TICK();
-#if IDIST_PHASES == 2
-                ctr.t_pre += tkA - tk0;                    // pop + peek + adjacency row
-                ctr.t_dist += tk1 - tkA;                   // visited set + compaction
-                ctr.t_post -= tk2;                         // + the tick after the push below: push alone
-#else
-                ctr.t_pre += tk1 - tk0;
-                ctr.t_dist += tk2 - tk1;
-                ctr.t_post -= tk2;                         // + the tick after the truncate below
-#endif
-                tk_on = true;
-#endif
                 ctr.n_dist += (uint32_t)na;
                 uint64_t key = kMaxKey;
                 if (fresh) key = ((uint64_t)act_dist[my] << 32) | nb_pid;
                 if (dlog.log) dlog_append(dlog, fresh ? tab_idx : -1, (uint32_t)(key >> 32));
                 w_push_keys(st, key, fresh);
-#if defined(IDIST_PHASES) && IDIST_PHASES == 2
-                if (tk_on) { ctr.t_post += IDIST_TICK(); tk_on = false; }
-#endif
             }
         } else {
             bool sure = false, maybe = false;
@@ -1599,9 +1562,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             }
         }
         w_truncate(st);                                    // :612
-#ifdef IDIST_PHASES
-        if (tk_on) ctr.t_post += IDIST_TICK();
-#endif
         if (++guard > ix.n + 64u) { st.status |= kStGuard; break; }
     }
 }
@@ -1681,10 +1641,17 @@ __device__ __attribute__((noinline)) void tile_stage(const float* __restrict__ p
             }
         }
     } else {
-        for (int u = 0; u < cnt; u++) {
-            const float* row = ix.points + (size_t)pids[u] * ix.stride;
-            for (int f = lane; f < nf4; f += 64)
-                *reinterpret_cast<float4*>(tile_addr(t, nb, first_slot + u, f)) = *reinterpret_cast<const float4*>(row + 4 * f);
+        // any dimension: the same 16 B of all (up to eight) candidates are requested together, 64 lanes x 8 rows = 8 KB per trip
+        const float* row[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) row[u] = ix.points + (size_t)pids[u < cnt ? u : cnt - 1] * ix.stride;
+        for (int f = lane; f < nf4; f += 64) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const float4*>(row[u] + 4 * f);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (u < cnt) *reinterpret_cast<float4*>(tile_addr(t, nb, first_slot + u, f)) = v[u];
         }
     }
 }

@@ -259,15 +259,9 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         if (lane == 0) {
             a.out_count[qi] = (uint32_t)cnt;
             if (a.out_counters) {
-#ifdef IDIST_PHASES
-                a.out_counters[3 * (size_t)qi + 0] = ctr.t_pre;
-                a.out_counters[3 * (size_t)qi + 1] = ctr.t_dist;
-                a.out_counters[3 * (size_t)qi + 2] = ctr.t_post;
-#else
                 a.out_counters[3 * (size_t)qi + 0] = ctr.n_dist;
                 a.out_counters[3 * (size_t)qi + 1] = ctr.n_exp0;
                 a.out_counters[3 * (size_t)qi + 2] = ctr.n_expU;
-#endif
             }
         }
         status |= st.status;

@@ -24,17 +24,18 @@ d_pts = bench.synth(torch, n, dim, 123456789, dev)
 q = bench.synth(torch, 2000, dim, 123456790, dev).cpu().numpy()
 torch.cuda.synchronize()
 CASES = {
-    "default": {},                                                              # two descent streams + selection stream
-    "r03_schedule": {"IDIST_BUILD_A_STREAMS": "1", "IDIST_BUILD_A2_STREAM": "0"},
-    "two_descent_streams_only": {"IDIST_BUILD_A2_STREAM": "0"},
-    "selection_stream_only": {"IDIST_BUILD_A_STREAMS": "1"},
+    "default": {},                                                              # extra streams in narrow steps only
+    "streams_off": {"IDIST_BUILD_STREAMS": "off"},                             # round 3's layout: one descent stream, one update stream
+    "streams_all": {"IDIST_BUILD_STREAMS": "all"},                             # extra streams in every step
     "cap16384": {"PB_MAX_BATCH": "16384"},
     "cap32768": {"PB_MAX_BATCH": "32768"},
-    "cap16384_r03_schedule": {"PB_MAX_BATCH": "16384", "IDIST_BUILD_A_STREAMS": "1", "IDIST_BUILD_A2_STREAM": "0"},
     "a_waves5": {"IDIST_BUILD_A_WAVES": "5"},
     "a_waves3": {"IDIST_BUILD_A_WAVES": "3"},
     "check": {"IDIST_BUILD_CHECK": "1"},                                        # both zero-layer copies must agree at the end
     "no_dlog": {"IDIST_BUILD_NO_DLOG": "1"},
+    "no_quad": {"IDIST_BUILD_QUAD": "0"},
+    # (the session of commit d4e16c2 — profiles/probe_r04b_build_schedule.jsonl — had the layout under two knobs:
+    #  r03_schedule = streams_off, default = streams_all, two_descent_streams_only / selection_stream_only = one of the two)
 }
 names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(CASES)
 truth = None

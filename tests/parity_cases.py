@@ -68,10 +68,34 @@ def pick_variants(variants, seed, keep):
     return [vs[0]] + picked
 
 
+_VARIANTS_LIB = None
+
+
+def variants_lib():
+    """libidist_variants.so: the product's sources + the walks no policy selects (`make variants`, built by
+    __graft_entry__.build()).  Test infrastructure; the product package never loads it."""
+    global _VARIANTS_LIB
+    if _VARIANTS_LIB is None:
+        from instant_distance_amd import _capi
+        path = os.path.join(os.path.dirname(_capi.LIB_PATH), "libidist_variants.so")
+        assert os.path.exists(path), "libidist_variants.so is missing: run __graft_entry__.build() (make -C instant-distance_amd/csrc variants)"
+        _VARIANTS_LIB = _capi.Lib(path)
+    return _VARIANTS_LIB
+
+
 @contextlib.contextmanager
 def search_variant(env):
+    """Environment of one walk variant.  Variants that exist in the test build only (IDIST_WALK=classic) run through
+    libidist_variants.so on the GPU: the same sources and struct layouts as libidist.so plus those kernels, so handles made
+    by either library are valid in the other (an index imported before the block is searched inside it, an index built
+    inside it is exported after it).  The emulator build holds every variant."""
     if isinstance(env, str):                     # a bare IDIST_LATENCY_NQ value
         env = {"IDIST_LATENCY_NQ": env}
+    swapped = None
+    if env.get("IDIST_WALK") == "classic" and not _emulated():
+        from instant_distance_amd import _capi
+        swapped = _capi._singleton
+        _capi._singleton = variants_lib()
     keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ", "IDIST_BUILD_A2",
             "IDIST_TAB_FORMAT", "IDIST_BUILD_NO_FAST", "IDIST_BUILD_QUAD", "IDIST_BUILD_A_REGS")
     old = {k: os.environ.get(k) for k in keys}
@@ -81,6 +105,9 @@ def search_variant(env):
     try:
         yield
     finally:
+        if swapped is not None:
+            from instant_distance_amd import _capi
+            _capi._singleton = swapped
         for k in keys:
             os.environ.pop(k, None)
             if old[k] is not None:

@@ -231,7 +231,8 @@ def test_build_batched_is_schedule_independent(eng, oracle, monkeypatch):
         # the published log, how early the descents' visited set spills: none of it may show in the graph
         envs += [{"IDIST_BUILD_A2": "tile"}, {"IDIST_BUILD_NO_DLOG": "1"}, {"IDIST_TAB_LOG2": "7"}]
     for env in envs:
-        with monkeypatch.context() as m:
+        # (IDIST_WALK=classic exists in the test build only: search_variant routes it to libidist_variants.so on the GPU)
+        with pc.search_variant({k_: v for k_, v in env.items() if k_ == "IDIST_WALK"}), monkeypatch.context() as m:
             m.setenv("IDIST_BUILD_CHECK", "1")
             for k_, v in env.items():
                 m.setenv(k_, v)
