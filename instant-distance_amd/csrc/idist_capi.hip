@@ -458,18 +458,38 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     const uint32_t dl_shift = tab_log2 + (tab16 ? 1u : 0u);
     const size_t smem = smem_bytes(ix->L.stride, wcap, true, 1u << tab_log2, vg.dirty_words);
 
-    // step B tile: as many selected rows on chip as fit 64 KiB of LDS next to 8 staging slots
+    // Tiles of steps B2 / A2 (tile kernel): selected rows kept on chip next to the staging slots.  A tile wave has to find LDS
+    // BESIDE the descents of the next step (four waves per CU of `smem` bytes each, resident for a whole launch): a tile that
+    // does not fit waits for that launch to drain and the pipeline runs serially — measured at 1024-d, where a 63-KB tile
+    // missed the 62 KB left by 1 KB and the full re-selections took 7.4 s of a 9.5-s build.  So: at most what is left of the
+    // CU's 160 KiB, at most 64 KiB; long runtime-geometry rows stage four candidates per round instead of eight.
+    const bool generic_geo = !((ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
+                               (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0));
+    const size_t lds_beside = (size_t)160 * 1024 > 4 * smem + 8 * 1024 ? (size_t)160 * 1024 - 4 * smem : 8 * 1024;
+    const size_t tile_budget = cap > 1 ? std::min<size_t>(64 * 1024, std::max<size_t>(lds_beside, 24 * 1024)) : 64 * 1024;
+    uint32_t fc = 8;
+    if (generic_geo && smem_bytes_update(ix->L.nb, 4, 8) > tile_budget) fc = 4;
     uint32_t rt = 8;
     if (const char* e = getenv("IDIST_BUILD_RT")) rt = (uint32_t)atoi(e);
-    while (rt > 0 && smem_bytes_update(ix->L.nb, rt) > 64 * 1024) rt--;
-    const size_t smemB = smem_bytes_update(ix->L.nb, rt);
+    while (rt > 0 && smem_bytes_update(ix->L.nb, rt, fc) > tile_budget) rt--;
+    size_t smemB = smem_bytes_update(ix->L.nb, rt, fc);
+    if (smemB > tile_budget) {                                   // does not fit beside the descents: take what a CU alone allows
+        rt = 8;
+        while (rt > 0 && smem_bytes_update(ix->L.nb, rt, fc) > 64 * 1024) rt--;
+        smemB = smem_bytes_update(ix->L.nb, rt, fc);
+    }
     if (smemB > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim %u needs %zu B of LDS per wave in the build (> 64 KiB)", ix->dim, smemB);
 
     // step A2 tile: the new point's selected set (up to 64 rows) — it is not memory bound, so favour rows on chip
     uint32_t rt2 = 16;
     if (const char* e = getenv("IDIST_BUILD_RT2")) rt2 = (uint32_t)atoi(e);
-    while (rt2 > 0 && smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction) > 64 * 1024) rt2--;
-    const size_t smemA2 = smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction);
+    while (rt2 > 0 && smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction, fc) > tile_budget) rt2--;
+    size_t smemA2 = smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction, fc);
+    if (smemA2 > tile_budget) {
+        rt2 = 16;
+        while (rt2 > 0 && smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction, fc) > 64 * 1024) rt2--;
+        smemA2 = smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction, fc);
+    }
     if (smemA2 > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim %u / ef_construction %u need %zu B of LDS per wave in the build (> 64 KiB)", ix->dim, cfg.ef_construction, smemA2);
 
     uint64_t* d_ext_work = nullptr;
@@ -636,6 +656,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     a.wbuf = d_wbuf;
     a.wcount = d_wcount;
     a.rt2 = rt2;
+    a.fc = fc;
     a.tie_cap = tie_cap;
     a.tie_spill = d_tie_spill;
     a.tie_spill_cap = tie_spill ? n : 0u;

@@ -409,6 +409,8 @@ struct BuildArgs {
     uint32_t* wcount;           // [max_batch]
     uint32_t rt;                // step B2: selected rows kept in the LDS tile
     uint32_t rt2;               // step A2: same for the new point's own selection
+    uint32_t fc;                // candidates staged per round in those tiles (8; fewer for long runtime-geometry rows, so that a tile
+                                // wave still finds LDS beside the descents)
     uint32_t chunk;             // step B: items per dequeue, 0 = by load (IDIST_BUILD_CHUNK, test knob)
     uint32_t tie_cap;           // capacity of the tie region of the descent (idist_config.tie_capacity)
     uint64_t* tie_spill;        // [slots][tie_spill_cap] or null: HBM bags for the ties beyond that capacity (WState::spill)
@@ -783,8 +785,8 @@ __global__ __launch_bounds__(64) void build_extend_kernel(IndexView ix, BuildArg
 // same selection re-gathered ~1.8 TB of selected rows from L2/HBM per 1M points, and a tile there
 // would have cost the HBM-bound descent its occupancy); then node.set + the inbox records.
 // ---------------------------------------------------------------------------
-__host__ __device__ inline size_t smem_bytes_select(uint32_t nb, uint32_t rt, uint32_t efc) {
-    return tile_floats(nb, rt + 8) * 4 + (size_t)(efc + 8 + 64 + 64) * 8 + 4 * 64 * 4;
+__host__ __device__ inline size_t smem_bytes_select(uint32_t nb, uint32_t rt, uint32_t efc, uint32_t fc = 8) {
+    return tile_floats(nb, rt + fc) * 4 + (size_t)(efc + 8 + 64 + 64) * 8 + 4 * 64 * 4;
 }
 
 template <int NB, int RS, int TAIL>
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(64) void build_select_kernel(IndexView ix, BuildArg
     const int nb = NB >= 0 ? NB : (int)ix.nb;
     Tile tile;
     tile.rt = (int)a.rt2;
-    tile.fc = 8;
+    tile.fc = NB >= 0 ? 8 : (int)a.fc;
     tile.slots = tile.rt + tile.fc;
     tile.blk = reinterpret_cast<float*>(smem_raw);
     tile.rem = tile.blk + (size_t)nb * tile.slots * 32;
@@ -1320,8 +1322,8 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
 // is symmetric), candidate rows are fetched 8 at a time into an LDS tile, and
 // the selected set stays in that tile, so every row crosses HBM once per update.
 // ---------------------------------------------------------------------------
-__host__ __device__ inline size_t smem_bytes_update(uint32_t nb, uint32_t rt) {
-    return tile_floats(nb, rt + 8) * 4 + (size_t)(kUpdW + 72 + 64 + 64 + 64) * 8 + 4 * 64 * 4;
+__host__ __device__ inline size_t smem_bytes_update(uint32_t nb, uint32_t rt, uint32_t fc = 8) {
+    return tile_floats(nb, rt + fc) * 4 + (size_t)(kUpdW + 72 + 64 + 64 + 64) * 8 + 4 * 64 * 4;
 }
 
 template <int NB, int RS, int TAIL>
@@ -1330,7 +1332,7 @@ __global__ __launch_bounds__(64) void build_update_kernel(IndexView ix, BuildArg
     const int nb = NB >= 0 ? NB : (int)ix.nb;
     Tile tile;
     tile.rt = (int)a.rt;
-    tile.fc = 8;
+    tile.fc = NB >= 0 ? 8 : (int)a.fc;
     tile.slots = tile.rt + tile.fc;
     tile.blk = reinterpret_cast<float*>(smem_raw);
     tile.rem = tile.blk + (size_t)nb * tile.slots * 32;

@@ -151,6 +151,7 @@ static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p 
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { auto o = *p; *p = o + v; return o; }
 static inline uint32_t atomicExch(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
 static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+static inline uint32_t atomicAnd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o & v; return o; }
 static inline uint32_t atomicCAS(uint32_t* p, uint32_t cmp, uint32_t v) {
     uint32_t o = *p;
     if (o == cmp) *p = v;
