@@ -430,6 +430,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     const VisGeom vg = vis_geometry(n);
     const Knobs knobs = Knobs::from_env();
     CHK(variants_check(knobs.classic));
+    // no compile-time instantiation of the row geometry (IDIST_DISPATCH): the runtime-geometry kernels
+    const bool rt_geometry = !((ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
+                               (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0));
+
     const uint32_t tie_cap = tie_capacity(cfg);
     const uint32_t wcap = cfg.ef_construction + 64 + tie_cap + 64;
     // The descents' on-chip visited set.  Quotient form (16-bit entries, idist_device.hpp q16_*) where n allows it: 16 KB hold
@@ -463,8 +467,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // does not fit waits for that launch to drain and the pipeline runs serially — measured at 1024-d, where a 63-KB tile
     // missed the 62 KB left by 1 KB and the full re-selections took 7.4 s of a 9.5-s build.  So: at most what is left of the
     // CU's 160 KiB, at most 64 KiB; long runtime-geometry rows stage four candidates per round instead of eight.
-    const bool generic_geo = !((ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
-                               (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0));
+    const bool generic_geo = rt_geometry;
     const size_t lds_beside = (size_t)160 * 1024 > 4 * smem + 8 * 1024 ? (size_t)160 * 1024 - 4 * smem : 8 * 1024;
     const size_t tile_budget = cap > 1 ? std::min<size_t>(64 * 1024, std::max<size_t>(lds_beside, 24 * 1024)) : 64 * 1024;
     uint32_t fc = 8;
@@ -528,7 +531,12 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     if (const char* e = getenv("IDIST_BUILD_A_WAVES")) a_waves = (uint32_t)std::min(8, std::max(1, atoi(e)));
     // the descent's register budget (quotient set only): 256 registers per wave (two waves fit a SIMD: the update stream's
     // waves find room on every SIMD) or 512 (IDIST_BUILD_A_REGS=512, more rounds in flight per wave).  C3: 1.26 vs 1.29-1.32 s
-    bool a_regs256 = tab16;
+    // Runtime-geometry rows (any dimension without a compile-time instantiation): the register tile, not the row, bounds what a
+    // wave keeps on the wire, and the 256-register tile (2 x 3 rounds x 4 blocks = 24 KB) is too little at four waves per
+    // CU: one 512-register wave per SIMD (2 x 4 x 8 = 64 KB each) builds 1M x 1024-d in 4.35 s instead of 9.6 s and 1M x 384-d
+    // in 1.98 s instead of 2.66 s (profiles/probe_r04d_build_dim*.jsonl) although the update stream then only runs where a
+    // descent wave has retired.
+    bool a_regs256 = tab16 && !rt_geometry;
     if (const char* e = getenv("IDIST_BUILD_A_REGS")) a_regs256 = tab16 && atoi(e) == 256;
     // steps of at most two insertions per CU run four waves per insertion (IDIST_BUILD_QUAD=0: never)
     const bool a_quad = !(getenv("IDIST_BUILD_QUAD") && getenv("IDIST_BUILD_QUAD")[0] == '0');

@@ -1399,27 +1399,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     // visited test-and-set in flight during the first distance pass (bitmap + Bloom filter only: the on-chip set answers at once)
     constexpr bool OVL = walk_mode(LAT) != kWalkClassic && !walk_vis_lds(LAT);
     uint32_t pf_pid = kInvalid, pf_row = kInvalid;
-    // Quotient set, once it overflows (long walks: ef_search beyond ~250 at 1M points): the ids that live in the HBM bitmap
-    // need a returning test-and-set — a second dependent round trip per expansion.  It is taken off the critical path by
-    // speculation: the adjacency row of the candidate most likely to be expanded next is at hand one expansion ahead
-    // (pf_row), so the test-and-set of ITS overflow-class ids is issued while the current expansion's rows are in flight.
-    // Right prediction (nearly always): their verdicts are there when the expansion begins, every new id goes into ONE
-    // distance pass.  Wrong prediction: the bits this speculation set (old value 0) are cleared again before anything
-    // else touches the bitmap.  Visited::insert semantics are unchanged: an id enters the set exactly when its expansion
-    // happens, and the verdict is the one a test-and-set at that moment would give (everything issued before the
-    // speculative atomics — the current expansion's own marks included — is ahead of them in the wave's order).
-    [[maybe_unused]] uint32_t sp_pid = kInvalid, sp_id = kInvalid, sp_vold = 0;   // uniform / per lane / per lane
-    [[maybe_unused]] bool sp_on = false, sp_any_full = false;                      // per lane / uniform, sticky for the layer
-    [[maybe_unused]] auto sp_undo = [&]() {                                        // wave-uniform call
-        const uint32_t bit = 1u << (sp_id & 31u);
-        uint32_t old = 0;
-        if (sp_on && (sp_vold & bit) == 0u) old = atomicAnd(&vis.bits[sp_id >> 5], ~bit);
-#ifndef IDIST_EMU
-        asm volatile("" ::"v"(old));                       // returning form, waited for: nothing overtakes the undo
-#endif
-        sp_pid = kInvalid;
-        sp_on = false;
-    };
     for (;;) {
         int ci = w_pop(st);                               // :599-604
         if (ci < 0 && st.spill_n && w_refill_ties(st)) ci = w_pop(st);   // live ties that did not fit the LDS region
@@ -1456,41 +1435,14 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             int stt = kQFound, tab_idx = -1;
             uint32_t vold = 0;
             const uint32_t vbit = 1u << (nb_pid & 31u);
-            // the speculation of the previous expansion: for this candidate (its row is pf_row: lanes line up) or not
-            const bool sp_hit = sp_pid != kInvalid && sp_pid == cpid;
-            if (sp_pid != kInvalid && !sp_hit) sp_undo();
-            bool have = false;                                                          // overflow-class verdict already at hand
             if (is_nb) {
                 if (nb_pid >= ix.n) st.status |= kStBadRow;
                 else {
                     stt = q16_lookup(vis, nb_pid);
-                    if (stt == kQFull) {
-                        if (sp_hit && sp_on && sp_id == nb_pid) { vold = sp_vold; have = true; }
-                        else vold = atomicOr(&vis.bits[nb_pid >> 5], vbit);
-                    }
+                    if (stt == kQFull) vold = atomicOr(&vis.bits[nb_pid >> 5], vbit);
                 }
             }
-            sp_pid = kInvalid;                                                          // consumed (or undone)
-            sp_on = false;
-            if (__ballot(is_nb && stt == kQFull)) sp_any_full = true;
-            const bool sure_room = is_nb && stt == kQRoom;
-            const bool sure_bm = is_nb && stt == kQFull && have && (vold & vbit) == 0u;  // new, and the bitmap already says so
-            const bool sure = sure_room || sure_bm, maybe = is_nb && stt == kQFull && !have;
-            bool spec_done = false;
-            auto speculate = [&]() {
-                spec_done = true;
-                if constexpr (PFA) {
-                    if (!sp_any_full || pf_pid == kInvalid) return;                     // (a set that has not overflowed yet: nothing to gain)
-                    const uint64_t pinv = __ballot(pf_row == kInvalid);
-                    const int pnv = pinv ? __builtin_ctzll(pinv) : 64;
-                    sp_pid = pf_pid;
-                    sp_id = pf_row;
-                    if (lane < pnv && pf_row < ix.n && q16_lookup(vis, pf_row) == kQFull) {
-                        sp_vold = atomicOr(&vis.bits[pf_row >> 5], 1u << (pf_row & 31u));
-                        sp_on = true;
-                    }
-                }
-            };
+            const bool sure = is_nb && stt == kQRoom, maybe = is_nb && stt == kQFull;
             uint32_t my_d = 0;
             const uint64_t sm = __ballot(sure);
             wave_sync();
@@ -1499,19 +1451,16 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 if (sure) act_pid[my] = nb_pid;                                         // keeps slot order
                 wave_sync();
                 auto mid = [&]() {
-                    if (sure_room && q16_insert(vis, nb_pid, tab_idx) == kQFull) {      // filled up by this very expansion
+                    if (sure && q16_insert(vis, nb_pid, tab_idx) == kQFull) {           // filled up by this very expansion
                         atomicOr(&vis.bits[nb_pid >> 5], vbit);
                         visited_note(vis, nb_pid);
                     }
-                    if (sure_bm) visited_note(vis, nb_pid);
-                    speculate();                                                        // after this expansion's own marks
                 };
                 if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, __popcll(sm), mid);
                 else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, __popcll(sm), mid);
                 wave_sync();
                 if (sure) my_d = act_dist[my];
             }
-            if (!spec_done) speculate();                                                // (no first pass: before the verdicts are waited for)
             const bool late = maybe && (vold & vbit) == 0u;
             if (late) visited_note(vis, nb_pid);
             const uint64_t lm = __ballot(late);
@@ -1615,7 +1564,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         w_truncate(st);                                    // :612
         if (++guard > ix.n + 64u) { st.status |= kStGuard; break; }
     }
-    if constexpr (walk_vis16(LAT)) { if (sp_pid != kInvalid) sp_undo(); }   // a speculation nobody came for
 }
 
 // n_dist / n_rows: work as executed here.  n_ref: distance calls as the REFERENCE makes them — `any` stops at the first

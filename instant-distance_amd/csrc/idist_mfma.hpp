@@ -436,53 +436,95 @@ __global__ __launch_bounds__(256) IDIST_A2M_ATTR void build_select_mfma_kernel(I
             }
         }
         block_sync();
-        // ---- the heuristic itself (wave 0): core/lib.rs:666-695 on the masks
+        // ---- the heuristic itself (wave 0): core/lib.rs:666-695 on the masks.  The verdict masks of all candidates sit in
+        //      registers (lane l: candidates l and 64 + l), so one step of the sequential loop is four readlanes and a few
+        //      scalar ops — no LDS round trip on the path from one verdict to the next (the loop used to read closer[] /
+        //      keys[] / pids[] from LDS every iteration: ~100 dependent round trips per new point with three waves idle).
+        //      Who pruned whom is kept as a candidate INDEX per lane; keys and pids are gathered after the loop, in parallel.
         if (wv == 0) {
+            const uint4 cl0 = *reinterpret_cast<const uint4*>(closer + lane * 4), cl1 = *reinterpret_cast<const uint4*>(closer + (64 + lane) * 4);
+            const uint4 un0 = *reinterpret_cast<const uint4*>(unsure + lane * 4), un1 = *reinterpret_cast<const uint4*>(unsure + (64 + lane) * 4);
             uint32_t selm[4] = {0u, 0u, 0u, 0u};
-            int nsel = 0, ndis = 0;
+            int nsel = 0, nproc = 0;
+            uint32_t pr0 = 0u, pr1 = 0u;                                 // lane l: index of the candidate that pruned l / 64 + l
             for (int i = 0; i < nw && nsel < kM2; i++) {
-                const uint64_t c = keys[i];
-                const uint32_t cd = (uint32_t)(c >> 32);
+                const int li = i & 63;
+                uint32_t m[4], u[4];
+                if (i < 64) {
+                    m[0] = readlane_u32(cl0.x, li); m[1] = readlane_u32(cl0.y, li); m[2] = readlane_u32(cl0.z, li); m[3] = readlane_u32(cl0.w, li);
+                    u[0] = readlane_u32(un0.x, li); u[1] = readlane_u32(un0.y, li); u[2] = readlane_u32(un0.z, li); u[3] = readlane_u32(un0.w, li);
+                } else {
+                    m[0] = readlane_u32(cl1.x, li); m[1] = readlane_u32(cl1.y, li); m[2] = readlane_u32(cl1.z, li); m[3] = readlane_u32(cl1.w, li);
+                    u[0] = readlane_u32(un1.x, li); u[1] = readlane_u32(un1.y, li); u[2] = readlane_u32(un1.z, li); u[3] = readlane_u32(un1.w, li);
+                }
                 bool pruned = false;
-                uint32_t pr_pid = 0;
-                for (int w = 0; w < 4 && !pruned; w++) {
-                    const uint32_t m = closer[i * 4 + w] & selm[w];
-                    if (m) { pruned = true; pr_pid = pids[w * 32 + __builtin_ctz(m)]; }
+                uint32_t pr_idx = 0;
+#pragma unroll
+                for (int w = 3; w >= 0; w--) {                           // (lowest word last: the first closer member wins, as before)
+                    const uint32_t mm = m[w] & selm[w];
+                    if (mm) { pruned = true; pr_idx = (uint32_t)(w * 32 + __builtin_ctz(mm)); }
                 }
-                bool staged = false;
-                for (int w = 0; w < 4 && !pruned; w++) {                 // pairs the filter could not decide: canonical distance
-                    const uint32_t m = unsure[i * 4 + w] & selm[w];
-                    if (!m) continue;
-                    wave_sync();
-                    if (!staged) {
-                        const float* prow = ix.points + (size_t)pids[i] * ix.stride;
-                        for (uint32_t o = lane * 4; o < ix.stride; o += 256)
-                            *reinterpret_cast<float4*>(qrow + o) = *reinterpret_cast<const float4*>(prow + o);
-                        staged = true;
+                if (!pruned && (((u[0] & selm[0]) | (u[1] & selm[1]) | (u[2] & selm[2]) | (u[3] & selm[3])) != 0u)) {
+                    // pairs the filter could not decide: canonical distance (rare: ~0.01 % of the pairs on float data)
+                    const uint32_t cd = (uint32_t)(keys[i] >> 32);
+                    bool staged = false;
+                    for (int w = 0; w < 4 && !pruned; w++) {
+                        const uint32_t mm = u[w] & selm[w];
+                        if (!mm) continue;
+                        wave_sync();
+                        if (!staged) {
+                            const float* prow = ix.points + (size_t)pids[i] * ix.stride;
+                            for (uint32_t o = lane * 4; o < ix.stride; o += 256)
+                                *reinterpret_cast<float4*>(qrow + o) = *reinterpret_cast<const float4*>(prow + o);
+                            staged = true;
+                        }
+                        const int cnt = __builtin_popcount(mm);
+                        if (lane < 32 && ((mm >> lane) & 1u)) act_pid[__builtin_popcount(mm & ((1u << lane) - 1u))] = pids[w * 32 + lane];
+                        wave_sync();
+                        dist_rounds<-1, -1, -1>(ix, qrow, act_pid, act_dist, cnt);     // rare: the small runtime-geometry form
+                        wave_sync();
+                        hc.n_dist += (uint32_t)cnt;
+                        const uint64_t cm = __ballot(lane < cnt && act_dist[lane] < cd);   // strict <, :678
+                        if (cm) {
+                            uint32_t rest = mm;                              // the ctz(cm)-th member of the list = that set bit of mm
+                            for (int k = __builtin_ctzll(cm); k > 0; k--) rest &= rest - 1u;
+                            pruned = true;
+                            pr_idx = (uint32_t)(w * 32 + __builtin_ctz(rest));
+                        }
                     }
-                    const int cnt = __builtin_popcount(m);
-                    if (lane < 32 && ((m >> lane) & 1u)) act_pid[__builtin_popcount(m & ((1u << lane) - 1u))] = pids[w * 32 + lane];
                     wave_sync();
-                    dist_rounds<-1, -1, -1>(ix, qrow, act_pid, act_dist, cnt);     // rare: the small runtime-geometry form
-                    wave_sync();
-                    hc.n_dist += (uint32_t)cnt;
-                    const uint64_t cm = __ballot(lane < cnt && act_dist[lane] < cd);   // strict <, :678
-                    if (cm) { pruned = true; pr_pid = act_pid[__builtin_ctzll(cm)]; }
                 }
-                wave_sync();
                 if (!pruned) {                                           // :681-684
-                    if (lane == 0) sel[nsel] = c;
                     selm[i >> 5] |= 1u << (i & 31);
                     nsel++;
-                } else {
-                    if (lane == 0 && ndis < kM2) { disc[ndis] = c; dprn[ndis] = pr_pid; }
-                    ndis++;
+                } else if (lane == li) {
+                    if (i < 64) pr0 = pr_idx; else pr1 = pr_idx;
                 }
+                nproc = i + 1;
             }
             hc.n_rows += (uint32_t)nw;
             hc.n_dist += (uint32_t)(nw * (nw - 1) / 2);                  // pairs decided (by the filter or exactly)
+            // selected-then-discarded lists, every lane placing its (up to) two candidates: position = rank among its kind
             const int n_selected = nsel;
+            int ndis = nproc - nsel;
             out_aux[lane] = 0u;
+            wave_sync();
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = h * 64 + lane;
+                if (i < nproc) {
+                    int below = 0;                                       // selected candidates in front of i
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const int lo = w * 32;
+                        const uint32_t msk = i >= lo + 32 ? 0xFFFFFFFFu : (i > lo ? ((1u << (i - lo)) - 1u) : 0u);
+                        below += __builtin_popcount(selm[w] & msk);
+                    }
+                    const bool is_sel = ((selm[i >> 5] >> (i & 31)) & 1u) != 0u;
+                    if (is_sel) sel[below] = keys[i];
+                    else if (i - below < kM2) { disc[i - below] = keys[i]; dprn[i - below] = pids[h ? pr1 : pr0]; }
+                }
+            }
             wave_sync();
             if (a.keep_pruned) {                                         // :687-695
                 if (ndis > kM2) ndis = kM2;

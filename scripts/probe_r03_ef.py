@@ -38,7 +38,7 @@ for name in which:
         h.set_ef_search(ef)
         o = (torch.empty(nq, ef, dtype=torch.int32, device=dev), torch.empty(nq, ef, dtype=torch.float32, device=dev),
              torch.empty(nq, dtype=torch.int32, device=dev), torch.zeros(nq, 3, dtype=torch.int32, device=dev))
-        row = {"config": name, "n": n, "dim": dim, "nq": nq, "ef": ef}
+        row = {"commit": bench.source_stamp(), "config": name, "n": n, "dim": dim, "nq": nq, "ef": ef}
         ref = None
         for nm, env in VARIANTS:
             os.environ.update(env)
