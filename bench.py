@@ -102,6 +102,60 @@ def effective_cores():
     return cores
 
 
+def measure_traffic(args, n, dim, nq, ef):
+    """roofline.traffic, measured in this session: two child passes of THIS command under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE cannot share a pass: TCC has four counter slots; PMC passes serialise kernels, so they cannot run inside the
+    timed process).  FETCH_SIZE is corrected with a factor calibrated IN THE SAME PASS on the same access pattern with a known
+    byte count (MI355X_MICROARCH.md §HBM: gfx950 tallies 128-B requests at 64 B; calibrate in your own pattern).  Returns
+    (dict | None, reason)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="idist_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", ctr, "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--traffic-child", "--config", args.config,
+                   "--n", str(n), "--dim", str(dim), "--nq", str(nq), "--ef", str(ef), "--max-batch", str(args.max_batch)]
+            r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return None, f"{ctr} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            known = [int(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("known_read_bytes_per_launch")]
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if not dbs:
+                return None, f"{ctr} pass left no results database"
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (ctr,)).fetchall()
+            sk = [v for k, v in rows if "search_kernel" in k]
+            cal = [v for k, v in rows if "distance_batch_kernel" in k]
+            if not sk:
+                return None, f"{ctr} pass saw no search_kernel dispatch"
+            full = [v for v in sk if v >= 0.5 * max(sk)]                    # the full-batch launches
+            got[ctr] = {"kb": sum(full) / len(full), "launches": len(full), "calib_kb": cal[-1] if cal else None, "known": known[-1] if known else None}
+        except Exception as e:  # noqa: BLE001
+            return None, f"{ctr} pass: {e!r}"[:300]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    f = got["FETCH_SIZE"]
+    if not f["calib_kb"] or not f["known"]:
+        return None, "no calibration dispatch in the FETCH_SIZE pass"
+    factor = f["known"] / (f["calib_kb"] * 1024.0)
+    fetch = f["kb"] * 1024.0 * factor
+    write = got["WRITE_SIZE"]["kb"] * 1024.0
+    return {"bytes_per_launch": int(fetch + write), "fetch_bytes_reported": int(f["kb"] * 1024), "fetch_correction_factor": round(factor, 4),
+            "fetch_bytes_corrected": int(fetch), "write_bytes_reported": int(write), "launches_averaged": f["launches"],
+            "calibration": "distance_batch_kernel over a random permutation of all rows of the same index in the same PMC pass: "
+                           f"{f['known']} B known, {int(f['calib_kb'] * 1024)} B reported",
+            "how": "two child passes of this command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, this box, this session; "
+                   "WRITE_SIZE uncalibrated (9 MB of 70 GB); fabric bytes (Infinity-Cache hits included)"}, None
+
+
 def scalar_calls(hnsw, ida, q_host, n_threads, calls):
     """The reference's own concurrency model (core/lib.rs:352-356): T host threads share ONE index, each owns a
     `Search` and issues scalar `Hnsw::search` calls (idist_search_batch with nq = 1, host pointers).  Returns the
@@ -172,6 +226,8 @@ def main():
     ap.add_argument("--check", action="store_true", help="add the `checks` object (size-independent properties; used by tests/)")
     ap.add_argument("--threads", default="1,4,16", help="host-thread counts of the scalar-call measurement ('' = skip)")
     ap.add_argument("--max-batch", type=int, default=0)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that fill roofline.traffic (N = 1 only)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child of measure_traffic()
     ap.add_argument("--no-inproc-rccl", action="store_true", help="N > 1: skip the in-process idist_replicate_rccl measurement after the run")
     args = ap.parse_args()
     cfgd = CONFIGS[args.config]
@@ -262,6 +318,20 @@ def main():
         pid, dd, cnt, ctr = outs
         hnsw.search_batch_device(s or search, d_q.data_ptr(), nq, pid.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
                                  ctr.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+    if args.traffic_child:
+        # profiled child of measure_traffic(): the same index, the same queries; one calibration gather with a known byte count
+        # (every row of the index once, in random order, through the 8-lanes-per-row loads of the walk), then full batches
+        hnsw.set_ef_search(args.ef or 100)
+        outs = alloc_out(args.ef or 100)
+        perm = torch.randperm(n, device=dev).to(torch.int32).cpu().numpy().astype(np.uint32).reshape(1, n)
+        hnsw.distances(d_q[:1].cpu().numpy(), perm)
+        print("known_read_bytes_per_launch", n * hnsw.info().row_stride * 4 + n * 4, flush=True)
+        for _ in range(2):
+            run(outs)
+        torch.cuda.synchronize()
+        search.check_status()
+        return
 
     # ---- ground truth (exact scan with the same canonical distance) + ef choice ----
     gt_req = cfgd["gtq"] if args.gt_queries < 0 else args.gt_queries
@@ -369,8 +439,13 @@ def main():
                 break
             except Exception:  # noqa: BLE001
                 continue
+        traffic, traffic_why = (None, "skipped (--no-traffic, N > 1, or a 10M-point configuration)")
+        if not args.no_traffic and world == 1 and n * dim <= 2_000_000_000:
+            traffic, traffic_why = measure_traffic(args, n, dim, nq, chosen)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_in_run": None,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic["bytes_per_launch"] if traffic else None,
+                    "traffic_over_algorithmic": round(traffic["bytes_per_launch"] / launch_bytes, 4) if traffic else None,
+                    "traffic_in_run": traffic if traffic else {"skipped": traffic_why},
                     "traffic_quoted": quoted, "traffic_source": quoted_src,
                     "mall_note": "FETCH_SIZE counts the L2's fabric-side requests: Infinity-Cache (MALL) hits are inside it, so "
                                  "'traffic' is fabric bytes, an upper bound of DRAM bytes; that is how an algorithmic rate can "

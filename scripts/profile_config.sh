@@ -7,7 +7,7 @@ repo="${GRAFT_REPO_ROOT:-/root/repo}"
 out=$repo/gpurun_out/$tag/$cfg
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 1500 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python $repo/bench.py --config $cfg --no-cpu-baseline --threads "" --steps 5 --warmup 2 > $out/trace.log 2>&1; echo "rc=$?"
+timeout 1500 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python $repo/bench.py --config $cfg --no-cpu-baseline --no-traffic --threads "" --steps 5 --warmup 2 > $out/trace.log 2>&1; echo "rc=$?"
 python $repo/scripts/summarize_profile.py $out $out/rocprof_summary_${tag}_$cfg "\`python bench.py --config $cfg --no-cpu-baseline --steps 5 --warmup 2\`" > $out/summary.json 2> $out/summary.err
 python - <<PY
 import json

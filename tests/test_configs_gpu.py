@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_config(name, extra=()):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", name, "--check", "--steps", "3", "--warmup", "1",
-           "--threads", "", "--cpu-sample", "512", "--cpu-build-sample", "0", *extra]
+           "--threads", "", "--cpu-sample", "512", "--cpu-build-sample", "0", "--no-traffic", *extra]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
