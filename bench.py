@@ -156,6 +156,38 @@ def measure_traffic(args, n, dim, nq, ef):
                    "WRITE_SIZE uncalibrated (9 MB of 70 GB); fabric bytes (Infinity-Cache hits included)"}, None
 
 
+def rccl_child(args, cfgd, torch):
+    """One process, N devices: build on device 0, idist_replicate_rccl to devices 1 .. N-1 (and once to device 0 itself, so that
+    the call is exercised on a single-GPU box too), then the last replica must answer a query sample exactly like the root."""
+    import instant_distance_amd as ida
+
+    ndev = min(args.rccl_child, torch.cuda.device_count())
+    n, dim = args.n or cfgd["n"], args.dim or cfgd["dim"]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    d_pts = synth(torch, n, dim, 123456789, dev)
+    torch.cuda.synchronize()
+    root = ida.Hnsw.from_device_points(d_pts.data_ptr(), n, dim, ida.Builder().max_batch(args.max_batch))
+    root.set_ef_search(args.ef or 100)
+    dests = list(range(1, ndev)) or [0]
+    t0 = time.perf_counter()
+    reps = root.replicate(dests, rccl=True)
+    wall = time.perf_counter() - t0
+    secs = root.last_replicate_seconds
+    q = synth(torch, 512, dim, 123456790, dev).cpu().numpy()
+    a = root.search_batch(q, ida.Search(), counters=True)
+    reps[-1].set_ef_search(args.ef or 100)
+    b = reps[-1].search_batch(q, ida.Search(), counters=True)
+    same = bool(np.array_equal(a.pid, b.pid) and np.array_equal(a.distance.view(np.uint32), b.distance.view(np.uint32)) and
+                np.array_equal(a.counters, b.counters))
+    info = root.info()
+    nbytes = int(n * info.row_stride * 4 + n * 256 + sum(list(info.layer_len)[: info.n_upper]) * 128)
+    print(json.dumps({"seconds": round(secs, 3), "wall_seconds_with_communicator_setup": round(wall, 3), "destinations": dests, "bytes": nbytes,
+                      "GBps_per_destination": round(nbytes / max(secs, 1e-9) / 1e9, 2), "last_replica_answers_identical_to_root": same,
+                      "note": "idist_replicate_rccl from ONE process (ncclCommInitAll + one grouped ncclBroadcast per buffer), measured after the "
+                              "per-rank processes exited"}), flush=True)
+
+
 def scalar_calls(hnsw, ida, q_host, n_threads, calls):
     """The reference's own concurrency model (core/lib.rs:352-356): T host threads share ONE index, each owns a
     `Search` and issues scalar `Hnsw::search` calls (idist_search_batch with nq = 1, host pointers).  Returns the
@@ -229,11 +261,14 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that fill roofline.traffic (N = 1 only)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child of measure_traffic()
     ap.add_argument("--no-inproc-rccl", action="store_true", help="N > 1: skip the in-process idist_replicate_rccl measurement after the run")
+    ap.add_argument("--rccl-child", type=int, default=0, help=argparse.SUPPRESS)        # internal: devices of the in-process replication child
     args = ap.parse_args()
     cfgd = CONFIGS[args.config]
 
     import torch
 
+    if args.rccl_child:
+        return rccl_child(args, cfgd, torch)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -612,38 +647,20 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        hung = False
         if world > 1 and not args.no_inproc_rccl:
-            # The C ABI's own replication (idist_replicate_rccl: one process, ncclCommInitAll over the devices, one grouped
-            # ncclBroadcast per buffer) next to the torch.distributed path above — measured when the other ranks are gone
-            # and their GPUs are free again, on a watchdog so that the line is printed whatever RCCL does.
-            res = {}
-
-            def inproc():
-                try:
-                    reps = hnsw.replicate(list(range(1, world)), rccl=True)
-                    secs = hnsw.last_replicate_seconds
-                    got = reps[-1].search_batch(sample_q_host, ida.Search(), counters=True)
-                    same = bool(np.array_equal(got.pid, sample_np[0].astype(np.uint32)) and
-                                np.array_equal(got.distance.view(np.uint32), sample_np[1].view(np.uint32)) and
-                                np.array_equal(got.counters, sample_np[3].astype(np.uint32)))
-                    res.update({"seconds": round(secs, 3), "destinations": world - 1,
-                                "GBps_per_destination": round(rep["replicate_bytes"] / max(secs, 1e-9) / 1e9, 2),
-                                "last_replica_answers_identical_to_rank0": same,
-                                "note": "idist_replicate_rccl from ONE process after the per-rank processes exited; communicator set-up excluded"})
-                    del reps
-                except Exception as e:  # noqa: BLE001
-                    res.update({"error": repr(e)[:300]})
-
-            sample_q_host = d_sample.cpu().numpy()
-            th = threading.Thread(target=inproc, daemon=True)
-            th.start()
-            th.join(timeout=240)
-            hung = th.is_alive()
-            out["config"]["replicate_rccl_in_process"] = {"skipped": "no answer within 240 s"} if hung else res
+            # The C ABI's own replication (idist_replicate_rccl: ONE process, ncclCommInitAll over the devices, one grouped
+            # ncclBroadcast per buffer) next to the torch.distributed path above.  Measured in a child process once the per-rank
+            # processes are gone and their GPUs are free again: whatever RCCL does there (a hang, a crash) costs this line
+            # nothing but the entry.
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-child", str(world), "--config", args.config, "--n", str(n),
+                                    "--dim", str(dim), "--ef", str(chosen), "--max-batch", str(args.max_batch)], capture_output=True, text=True, timeout=420)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                out["config"]["replicate_rccl_in_process"] = json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:  # noqa: BLE001
+                out["config"]["replicate_rccl_in_process"] = {"skipped": repr(e)[:200]}
         print(json.dumps(out), flush=True)
-        if hung:
-            os._exit(0)
 
 
 if __name__ == "__main__":

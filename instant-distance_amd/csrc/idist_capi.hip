@@ -946,10 +946,16 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
 // Which walk serves a wide batch (profiles/probe_r02_ef_paths_onchip_vs_bitmap.jsonl, probe_r02_configs_c2_c4_c5.jsonl):
 //   * a search visits ~53 * ef_search + 600 nodes; the 8192-id on-chip set is frozen at 7168 and the rest of the walk
 //     test-and-sets the bitmap.  The fat on-chip waves still win while a row fetch outweighs that extra round trip:
-//     up to ef_search ~ 180 at 128-d, ~ 550 at 300-d, beyond 200 at 768-d  =>  ef_search <= 1.5 x row floats;
+//     up to ef_search ~ 180 at 128-d, ~ 550 at 300-d (id set; ~ 600 with the quotient set), beyond 200 at 768-d;
 //   * an index that sits in the Infinity Cache (100k x 128: 51 MB) is served faster by 16 small waves per CU
 //     (4.2 vs 5.0 ms per 10k queries): the on-chip walk is for HBM-resident indexes.
-inline uint32_t on_chip_max_ef(uint32_t stride_floats) { return std::min(1536u, std::max(160u, stride_floats * 3u / 2u)); }
+//   * round 4, quotient set (profiles/probe_r04f_ef_crossover_c3.jsonl): at 300-d the fat on-chip waves still win at ef_search
+//     550 (0.673 vs 0.636 of spec) and lose at 650 (0.608 vs 0.635): the crossover moved from ~1.5 to ~2 x row floats; at
+//     128-d it stays where round 2 measured it (~180 = 1.4 x).  One line through both points, within [160, 1536].
+inline uint32_t on_chip_max_ef(uint32_t stride_floats) {
+    const int ef = (int)stride_floats * 61 / 25 - 132;
+    return (uint32_t)std::min(1536, std::max(160, ef));
+}
 constexpr size_t kCacheResidentBytes = (size_t)128 << 20;
 
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,

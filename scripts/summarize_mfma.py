@@ -65,4 +65,8 @@ for case in ("build", "bf"):
             d["mfma_TFLOPs"] = round(flops / (t2 * 1e-3) / 1e12, 2)
             d["mfma_frac_of_157TF"] = round(flops / (t2 * 1e-3) / 157.3e12, 4)
     res[case] = r
+try:
+    res["commit"] = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")).read().strip()
+except OSError:
+    res["commit"] = None
 print(json.dumps(res, indent=1))

@@ -11,6 +11,10 @@ out = sys.argv[1]
 dest = sys.argv[2] if len(sys.argv) > 2 else None
 what = sys.argv[3] if len(sys.argv) > 3 else "`python bench.py` (C3: 1M x 300-d, 10k queries, ef_search=100)"
 res = {}
+try:   # the commit the profiled tree was built from (scripts/stamp.py; .git does not travel to the GPU box)
+    res["commit"] = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")).read().strip()
+except OSError:
+    res["commit"] = None
 KEYS = ("search_kernel", "build_insert_kernel", "build_select_mfma_kernel", "copy_rows_kernel", "build_select_kernel", "build_update_fast_kernel", "build_update_simple_kernel", "build_update_kernel",
         "bruteforce_kernel", "distance_batch_kernel", "mfma_dist_kernel", "rerank_kernel", "kth_threshold_kernel",
         "row_norms_kernel", "permute_rows_kernel", "snapshot_kernel", "validate_rows_kernel")
@@ -125,9 +129,12 @@ print(json.dumps(res, indent=1))
 if dest:
     json.dump(res, open(dest + ".json", "w"), indent=1)
     if "traffic" in res:
+        res["traffic"]["commit"] = res["commit"]
         json.dump(res["traffic"], open(os.path.join(os.path.dirname(dest), "traffic_" + os.path.basename(dest).split("_")[-1] + ".json"), "w"), indent=1)
+    if isinstance(res.get("traffic"), dict):
+        res["traffic"]["commit"] = res["commit"]
     with open(dest + ".md", "w") as f:
-        f.write(f"# rocprofv3 summary ({os.path.basename(dest)})\n\nCommand: {what} under "
+        f.write(f"# rocprofv3 summary ({os.path.basename(dest)})\n\nCommit: `{res['commit']}`.  Command: {what} under "
                 "`rocprofv3 --kernel-trace --stats`" + (", then separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / TCC passes" if res["pmc_FETCH_SIZE"] else "") + ".\n\n")
         f.write("## kernel-trace --stats (top kernels)\n\n| kernel | calls | total µs | avg µs | % |\n|---|---|---|---|---|\n")
         for r in res.get("kernel_stats", []):
