@@ -99,6 +99,11 @@ pub enum Metric {
     L2 = 1,
 }
 
+/// Hardware queues: every `Search` owns a HIP stream, and the runtime multiplexes a process's streams onto
+/// `GPU_MAX_HW_QUEUES` queues (default 4, read once when the HIP runtime starts).  A host with more than four searching
+/// threads sets it before its first call into this module — `std::env::set_var("GPU_MAX_HW_QUEUES", "16")` at the top of
+/// `main`, or in the service's environment.  libidist does not edit the process environment itself.
+///
 /// True if a gfx950 device and libidist.so are usable; `Hnsw::new` falls back to the CPU code otherwise.
 pub fn available() -> bool {
     let mut n = 0i32;
