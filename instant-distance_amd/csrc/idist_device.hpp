@@ -1360,6 +1360,10 @@ __device__ __forceinline__ void w_push_merge(WState& st, uint64_t key, uint64_t 
     st.plen = plen + nacc;
     if (first < st.cursor) st.cursor = first;
 }
+// MAXC: chunks of 64 entries the one-pass merge may hold in registers (two dwords + a counter per chunk and lane).  The fat
+// on-chip waves (512 registers) take 16 — a `nearest` of up to 1024 entries, i.e. ef_search up to ~900, is merged in one pass
+// instead of one ranked, shifted insertion per accepted key (at ef_search 800 that was most of an expansion's time).
+template <int MAXC = kPushChunks>
 __device__ __forceinline__ void w_push_keys(WState& st, uint64_t key, bool has) {
     // entries that cannot have rank < ef even now never will (W only improves)
     const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
@@ -1371,6 +1375,7 @@ __device__ __forceinline__ void w_push_keys(WState& st, uint64_t key, bool has) 
     if (plen <= 128) return w_push_merge<2>(st, key, pm);
     if (plen <= 256) return w_push_merge<4>(st, key, pm);
     if (plen <= 64 * kPushChunks) return w_push_merge<kPushChunks>(st, key, pm);
+    if constexpr (MAXC >= 16) { if (plen <= 64 * 16) return w_push_merge<16>(st, key, pm); }
     while (pm) {
         const int i = __builtin_ctzll(pm);
         pm &= pm - 1ull;
@@ -1387,6 +1392,7 @@ __device__ __forceinline__ void w_push_keys(WState& st, uint64_t key, bool has) 
 //   * neighbours the Bloom filter proves new go straight to the distance rounds while the visited bytes of
 //     the "maybe" ones are still in flight (those that turn out new get a second, usually empty, pass);
 //   * all rounds of a pass are requested together (dist_rounds_inflight).
+template <int WALK> constexpr int push_chunks() { return walk_vis_lds(WALK) && walk_waves(WALK) == 1 && !walk_quad(WALK) ? 16 : kPushChunks; }
 template <int NB, int RS, int TAIL, int LAT = 0>
 __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t* rows, int row_stride, int links,
                                              const float* q, WState& st, Visited& vis, uint32_t* act_pid,
@@ -1481,7 +1487,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 uint64_t key = kMaxKey;
                 if (fresh) key = ((uint64_t)my_d << 32) | nb_pid;
                 if (dlog.log) dlog_append(dlog, fresh ? tab_idx : -1, my_d);            // (ids that went to the bitmap have no index)
-                w_push_keys(st, key, fresh);
+                w_push_keys<push_chunks<LAT>()>(st, key, fresh);
             }
         } else if constexpr (!OVL) {
             // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
@@ -1516,7 +1522,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 uint64_t key = kMaxKey;
                 if (fresh) key = ((uint64_t)act_dist[my] << 32) | nb_pid;
                 if (dlog.log) dlog_append(dlog, fresh ? tab_idx : -1, (uint32_t)(key >> 32));
-                w_push_keys(st, key, fresh);
+                w_push_keys<push_chunks<LAT>()>(st, key, fresh);
             }
         } else {
             bool sure = false, maybe = false;
@@ -1558,7 +1564,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 uint64_t key = kMaxKey;
                 if (fresh) key = ((uint64_t)my_d << 32) | nb_pid;
                 if (dlog.log) dlog_append(dlog, fresh ? vis_index(vis, nb_pid) : -1, my_d);
-                w_push_keys(st, key, fresh);
+                w_push_keys<push_chunks<LAT>()>(st, key, fresh);
             }
         }
         w_truncate(st);                                    // :612

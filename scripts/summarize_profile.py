@@ -78,7 +78,7 @@ except Exception as e:  # noqa: BLE001
 # the bench line printed by the TRACED run itself: its HIP-event kernel time must agree with the trace
 try:
     for line in open(os.path.join(out, "trace.log")):
-        if line.startswith('{"metric"'):
+        if line.startswith("{") and '"metric"' in line:
             res["bench_traced_run"] = json.loads(line)
     for f in dbs("trace"):
         cur = sqlite3.connect(f).cursor()
