@@ -220,11 +220,13 @@ struct Knobs {
     bool tab_q16 = false;         // IDIST_TAB_FORMAT=q16: quotients wherever they apply, also where the policy would keep ids
     bool no_zero_copy = false;    // IDIST_NO_ZERO_COPY=1: narrow host-pointer batches take the general (staged) path too (test / A-B knob)
     int ea = 0;                   // IDIST_EA=<k> (measurement builds only, -DIDIST_EA_PROBE): early abandon after k blocks of a 300-d row
+    uint32_t w2_ef = 0xFFFFFFFFu; // IDIST_W2_EF=<ef>: from this ef_search on, wide on-chip batches run two 256-register waves per SIMD (A/B knob; default: policy)
     uint32_t quad_nq = 0xFFFFFFFFu;   // IDIST_QUAD_NQ: batches up to this many queries run four waves per query (default: two
                                       // workgroups per CU, one for 768-d rows; 0 = never)
     static Knobs from_env() {
         Knobs k;
         if (const char* e = getenv("IDIST_EA")) k.ea = atoi(e);
+        if (const char* e = getenv("IDIST_W2_EF")) k.w2_ef = (uint32_t)strtoul(e, nullptr, 10);
         if (const char* e = getenv("IDIST_LATENCY_NQ")) k.latency_nq = (uint32_t)strtoul(e, nullptr, 10);
         if (const char* e = getenv("IDIST_QUAD_NQ")) k.quad_nq = (uint32_t)std::min<unsigned long>(strtoul(e, nullptr, 10), 0xFFFFFFFEul);
         if (const char* e = getenv("IDIST_WALK")) k.classic = e[0] == 'c';      // (honoured by the test build only, see variants_check)
@@ -670,7 +672,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     a.tie_spill_cap = tie_spill ? n : 0u;
     if (const char* e = getenv("IDIST_BUILD_CHUNK")) a.chunk = (uint32_t)atoi(e);
     const size_t smemF = smem_bytes_update_fast(ix->L.stride);
-    const bool classic = knobs.classic;
+    [[maybe_unused]] const bool classic = knobs.classic;   // (test build: IDIST_VARIANT_BUILD)
     const bool no_fast = getenv("IDIST_BUILD_NO_FAST") != nullptr;   // test knob: route every update through B2
     a.stats = d_stats;
 
@@ -949,14 +951,18 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
 //     up to ef_search ~ 180 at 128-d, ~ 550 at 300-d (id set; ~ 600 with the quotient set), beyond 200 at 768-d;
 //   * an index that sits in the Infinity Cache (100k x 128: 51 MB) is served faster by 16 small waves per CU
 //     (4.2 vs 5.0 ms per 10k queries): the on-chip walk is for HBM-resident indexes.
-//   * round 4, quotient set (profiles/probe_r04f_ef_crossover_c3.jsonl): at 300-d the fat on-chip waves still win at ef_search
-//     550 (0.673 vs 0.636 of spec) and lose at 650 (0.608 vs 0.635): the crossover moved from ~1.5 to ~2 x row floats; at
-//     128-d it stays where round 2 measured it (~180 = 1.4 x).  One line through both points, within [160, 1536].
+//   * round 4 (profiles/probe_r04f_ef_crossover_c3.jsonl, probe_r04i_ef_paths_wide_merge_c3.jsonl): with the quotient set the
+//     crossover at 300-d moved from ~1.5 to ~2 x row floats, and once the fat waves merged a `nearest` of up to 1024 entries in
+//     one pass (w_push_merge<16>) the on-chip walk stayed ahead of the bitmap walk up to ef_search 1000 (0.651 / 0.637 / 0.625
+//     vs 0.628 / 0.620 / 0.611 of spec at 650 / 800 / 1000).  Rows of >= 256 floats: on chip while that merge covers the list
+//     (ef_search <= 1024 - ties); shorter rows: the line through the 128-d (~180) and 300-d (~600) crossovers.
 inline uint32_t on_chip_max_ef(uint32_t stride_floats) {
+    if (stride_floats >= 256u) return 1024u - 2u * (uint32_t)kTieCap;
     const int ef = (int)stride_floats * 61 / 25 - 132;
     return (uint32_t)std::min(1536, std::max(160, ef));
 }
 constexpr size_t kCacheResidentBytes = (size_t)128 << 20;
+constexpr uint32_t kLongWalkEf = 0xFFFFFFFFu;   // ef_search from which wide on-chip batches run two thinner waves per SIMD (see launch_search)
 
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
                            uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream,
@@ -998,7 +1004,13 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // 1-2 % (ef_search = 100: 10.25 vs 10.42 ms per 10k queries at C3, profiles/probe_r03a_ef_paths_*)
     const bool ids_suffice = 53u * ef + 600u <= (7u << tab_log2) / 8u;
     const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits) && (ctx->knobs.tab_q16 || ctx->knobs.tab_log2 || !ids_suffice);
-    uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (on_chip ? 4u : 16u));   // quad: two workgroups per CU where registers allow
+    // Long walks (ef_search in the hundreds): an expansion costs a wave 9-10 us whatever it fetches, and it fetches fewer new rows
+    // the longer the walk runs — more, thinner waves (two 256-register waves per SIMD, as many as the CU's LDS holds) keep more
+    // expansions in flight than one fat wave per SIMD.
+    const uint32_t w2_from = ctx->knobs.w2_ef != 0xFFFFFFFFu ? ctx->knobs.w2_ef : kLongWalkEf;
+    const bool w2 = on_chip && q16 && !quad && !ctx->knobs.classic && ef >= w2_from;
+    const uint32_t w2_per_cu = (uint32_t)std::min<size_t>(8, (size_t)160 * 1024 / smem_bytes(ix->L.stride, a.wcap, false, 1u << std::max(tab_log2, 5u), a.vis.dirty_words));
+    uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (w2 ? std::max(w2_per_cu, 4u) : (on_chip ? 4u : 16u)));   // quad: two workgroups per CU where registers allow
     if (ctx->tie_spill) {
         // one bag of n keys per slot (a walk can hold every point as a tie at most once); the slots that fit 1 GiB
         const uint32_t fit = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)std::max(ix->n, 1u) * 8));
@@ -1031,7 +1043,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
                                    a.vis.dirty_words);
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_search need %zu B of LDS per wave (> 64 KiB)", smem);
     const uint32_t grid = std::min(std::min(nq, ctx->slots), resident);
-    const bool classic = ctx->knobs.classic;
+    [[maybe_unused]] const bool classic = ctx->knobs.classic;   // (test build: IDIST_VARIANT_SEARCH_*)
     IndexView view = ix->view();
     a.queue_base = ctx->queue_base;
     a.status_host = status_host && grid <= idist_search_ctx::kIoStatusSlots ? status_host : nullptr;
@@ -1073,7 +1085,10 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
         } else if (quad) {                                                                         \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, true)>; \
             IDIST_LAUNCH(kS, grid, 256, smem, stream, view, a);                                    \
-        } IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_) else if (on_chip && q16) {              \
+        } IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_) else if (w2) {                          \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+        } else if (on_chip && q16) {                                                               \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } IDIST_VARIANT_SEARCH_ONCHIP_IDS(NB_, RS_, TAIL_) else if (on_chip) {                     \

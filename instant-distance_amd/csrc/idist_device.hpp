@@ -1392,7 +1392,7 @@ __device__ __forceinline__ void w_push_keys(WState& st, uint64_t key, bool has) 
 //   * neighbours the Bloom filter proves new go straight to the distance rounds while the visited bytes of
 //     the "maybe" ones are still in flight (those that turn out new get a second, usually empty, pass);
 //   * all rounds of a pass are requested together (dist_rounds_inflight).
-template <int WALK> constexpr int push_chunks() { return walk_vis_lds(WALK) && walk_waves(WALK) == 1 && !walk_quad(WALK) ? 16 : kPushChunks; }
+template <int WALK> constexpr int push_chunks() { return walk_vis_lds(WALK) && (walk_waves(WALK) == 1 || walk_waves(WALK) == 2) && !walk_quad(WALK) ? 16 : kPushChunks; }
 template <int NB, int RS, int TAIL, int LAT = 0>
 __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t* rows, int row_stride, int links,
                                              const float* q, WState& st, Visited& vis, uint32_t* act_pid,

@@ -22,8 +22,9 @@ os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
 fo = open(out_path, "a")
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
-VARIANTS = (("q16", {"IDIST_VISITED": "onchip"}), ("ids", {"IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "ids"}),
-            ("bitmap", {"IDIST_VISITED": "bitmap"}), ("default", {}))
+VARIANTS = (("q16", {"IDIST_VISITED": "onchip", "IDIST_W2_EF": "4000000000"}), ("q16w2", {"IDIST_VISITED": "onchip", "IDIST_W2_EF": "0"}),
+            ("ids", {"IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "ids"}), ("bitmap", {"IDIST_VISITED": "bitmap"}), ("default", {}))
+# (q16: one 512-register wave per SIMD; q16w2: two 256-register waves per SIMD, as many as the CU's LDS holds — round 4)
 REPS = int(os.environ.get("PB_REPS", 3))
 
 for name in which:
