@@ -954,15 +954,16 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
 //   * round 4 (profiles/probe_r04f_ef_crossover_c3.jsonl, probe_r04i_ef_paths_wide_merge_c3.jsonl): with the quotient set the
 //     crossover at 300-d moved from ~1.5 to ~2 x row floats, and once the fat waves merged a `nearest` of up to 1024 entries in
 //     one pass (w_push_merge<16>) the on-chip walk stayed ahead of the bitmap walk up to ef_search 1000 (0.651 / 0.637 / 0.625
-//     vs 0.628 / 0.620 / 0.611 of spec at 650 / 800 / 1000).  Rows of >= 256 floats: on chip while that merge covers the list
-//     (ef_search <= 1024 - ties); shorter rows: the line through the 128-d (~180) and 300-d (~600) crossovers.
+//     vs 0.628 / 0.620 / 0.611 of spec at 650 / 800 / 1000; beyond the merge's reach too: 0.628 vs 0.565 at ef 1000 in
+//     probe_r04k).  Rows of >= 256 floats: on chip as far as LDS allows; shorter rows: the line through the 128-d (~180) and
+//     300-d (~600) crossovers.
 inline uint32_t on_chip_max_ef(uint32_t stride_floats) {
-    if (stride_floats >= 256u) return 1024u - 2u * (uint32_t)kTieCap;
+    if (stride_floats >= 256u) return 1536u;       // (as far as W and the set fit a wave's LDS: tab_fit in launch_search)
     const int ef = (int)stride_floats * 61 / 25 - 132;
     return (uint32_t)std::min(1536, std::max(160, ef));
 }
 constexpr size_t kCacheResidentBytes = (size_t)128 << 20;
-constexpr uint32_t kLongWalkEf = 0xFFFFFFFFu;   // ef_search from which wide on-chip batches run two thinner waves per SIMD (see launch_search)
+constexpr uint32_t kLongWalkEf = 512u;   // ef_search from which wide on-chip batches run two thinner waves per SIMD (see launch_search)
 
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
                            uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream,
@@ -1007,7 +1008,11 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // Long walks (ef_search in the hundreds): an expansion costs a wave 9-10 us whatever it fetches, and it fetches fewer new rows
     // the longer the walk runs — more, thinner waves (two 256-register waves per SIMD, as many as the CU's LDS holds) keep more
     // expansions in flight than one fat wave per SIMD.
-    const uint32_t w2_from = ctx->knobs.w2_ef != 0xFFFFFFFFu ? ctx->knobs.w2_ef : kLongWalkEf;
+    // Measured at 300-d (profiles/probe_r04k_ef_paths_two_waves_per_simd_c3.jsonl: ef 650 / 800 / 1000 at 0.704 / 0.690 / 0.651 of
+    // spec against 0.653 / 0.639 / 0.628 for the fat waves, 0.787 against 0.795 at ef 400): from ef_search 512 on, for that row
+    // geometry; other geometries keep the fat waves until they are measured (IDIST_W2_EF forces either way).
+    const bool w2_geometry = ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1;
+    const uint32_t w2_from = ctx->knobs.w2_ef != 0xFFFFFFFFu ? ctx->knobs.w2_ef : (w2_geometry ? kLongWalkEf : 0xFFFFFFFFu);
     const bool w2 = on_chip && q16 && !quad && !ctx->knobs.classic && ef >= w2_from;
     const uint32_t w2_per_cu = (uint32_t)std::min<size_t>(8, (size_t)160 * 1024 / smem_bytes(ix->L.stride, a.wcap, false, 1u << std::max(tab_log2, 5u), a.vis.dirty_words));
     uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (w2 ? std::max(w2_per_cu, 4u) : (on_chip ? 4u : 16u)));   // quad: two workgroups per CU where registers allow

@@ -18,6 +18,8 @@ INVALID = 0xFFFFFFFF
 SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by index size and ef_search)", {}),
                    ("on-chip, quotient set", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "q16"}),
                    ("four waves per query, quotient set", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_FORMAT": "q16"}),
+                   ("long-walk form: two 256-register waves per SIMD on the quotient set (policy: ef_search >= 512 at 300-d)",
+                    {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "q16", "IDIST_W2_EF": "0"}),
                    ("four waves per query, 512-B quotient set (256 ids) then bitmap", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_LOG2": "7"}),
                    ("on-chip classic", {"IDIST_WALK": "classic", "IDIST_VISITED": "onchip"}),
                    ("on-chip, full ids", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "ids"}),
@@ -97,7 +99,7 @@ def search_variant(env):
         swapped = _capi._singleton
         _capi._singleton = variants_lib()
     keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ", "IDIST_BUILD_A2",
-            "IDIST_TAB_FORMAT", "IDIST_BUILD_NO_FAST", "IDIST_BUILD_QUAD", "IDIST_BUILD_A_REGS")
+            "IDIST_TAB_FORMAT", "IDIST_BUILD_NO_FAST", "IDIST_BUILD_QUAD", "IDIST_BUILD_A_REGS", "IDIST_W2_EF")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)
