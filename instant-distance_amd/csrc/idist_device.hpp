@@ -1235,11 +1235,31 @@ struct Counters {
 // barriers per expansion:
 //     leader: act_pid[0..na) and ctl->na written | B1 | its share of the pass | B2 | reads act_dist, pushes, ...
 //     helper:                         (waits)     | B1 | its share of the pass | B2 | (waits at the next B1)
-// ctl->na = kQuadExit releases the helpers when the leader's work queue is empty.  Decisions, their order and the
+// kQuadExit releases the helpers when the leader's work queue is empty.  Decisions, their order and the
 // arithmetic per row are those of the other variants: results are bit-identical.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kQuadExit = 0xFFFFFFFFu;
-struct QuadCtl { uint32_t na; uint32_t pad[3]; };
+// Round 4 — the helpers also work AHEAD.  The leader's share of an expansion that is not a distance pass (pop, visited set,
+// push: ~1.9 us of ~4.1) used to leave three SIMDs idle.  Now the leader names the candidate it expects to pop next (the first
+// un-expanded entry behind the current one; a replay of the walk says it is the one 89 % of the time at ef 100, 97 % at ef 400)
+// and hands its adjacency row over; while the leader pushes, the helpers look that row's ids up in the visited set (read only),
+// compact the new ones in slot order and compute their distances.  If the next pop is that candidate, the leader takes ids and
+// distances as they are — nothing changed the visited set in between (ids enter it inside distance passes only), so they are
+// exactly what its own look-up and pass would produce — inserts the ids, pushes in slot order, and no distance pass stands
+// between two pushes.  Otherwise the results are ignored.  Speculation is only asked for while the on-chip set answers every
+// look-up alone (no id in the bitmap: narrow batches at ef_search ~100 never get there).
+// Commands, each behind one workgroup barrier A (helpers loop: A, read command, act):
+//     kQuadPass(na)  all four waves take their share of act_pid[0..na), then barrier B
+//     kQuadSpec      helpers: speculate on ctl->spec_row (the row of ctl->spec_pid)
+//     kQuadTake      nothing — the barrier itself is the hand-over: helpers arrive at A when their speculation is done
+//     kQuadExit      helpers leave
+enum : uint32_t { kQuadPass = 0, kQuadSpec = 1, kQuadTake = 2, kQuadExit = 3 };
+constexpr uint32_t kSpecAbort = 0xFFFFFFFFu;            // spec_n: the row holds an id only the bitmap can answer for
+struct QuadCtl {
+    uint32_t cmd, na, spec_n, pad;
+    uint32_t spec_row[64];                               // leader -> helpers: the predicted candidate's adjacency row (slot order)
+    uint32_t spec_new[64];                               // helpers -> leader: its new ids, compacted in slot order
+    uint32_t spec_dist[64];                              // ... and their canonical distance bits
+};
 template <int NB, int RS, int TAIL, class Mid = NoMid>
 __device__ __forceinline__ void quad_dist_pass(const IndexView& ix, const float* q, QuadCtl* ctl, const uint32_t* act_pid,
                                                uint32_t* act_dist, int na, Mid mid = Mid()) {
@@ -1247,25 +1267,73 @@ __device__ __forceinline__ void quad_dist_pass(const IndexView& ix, const float*
         dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0, mid);
         return;
     }
-    if (lane_id() == 0) ctl->na = (uint32_t)na;
-    block_sync();                                                      // B1
+    if (lane_id() == 0) { ctl->cmd = kQuadPass; ctl->na = (uint32_t)na; }
+    block_sync();                                                      // A
     dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0, mid);
-    block_sync();                                                      // B2
+    block_sync();                                                      // B
 }
+// leader: hand the predicted candidate's row to the helpers (row_id: this lane's slot of it, kInvalid beyond its end)
+__device__ __forceinline__ void quad_post_spec(QuadCtl* ctl, uint32_t row_id) {
+    ctl->spec_row[lane_id()] = row_id;
+    if (lane_id() == 0) ctl->cmd = kQuadSpec;
+    block_sync();                                                      // A
+}
+// leader: wait for the speculation it asked for; number of new ids in ctl->spec_new / spec_dist, or kSpecAbort
+__device__ __forceinline__ uint32_t quad_take_spec(QuadCtl* ctl) {
+    if (lane_id() == 0) ctl->cmd = kQuadTake;
+    block_sync();                                                      // A: the helpers arrive when they are done
+    return uniform_u32(ctl->spec_n);
+}
+// the helpers' three-way split of a speculated list: wave wv (1..3) takes rounds wv - 1, wv + 2, ... of 8 rows
 template <int NB, int RS, int TAIL>
-__device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const float* q, const QuadCtl* ctl, const uint32_t* act_pid,
-                                                 uint32_t* act_dist, int wv) {
+__device__ __forceinline__ void dist_rounds_spec(const IndexView& ix, const float* q, const uint32_t* pids, uint32_t* dists, int na, int wv) {
+    if constexpr (NB >= 0) {
+        constexpr int RIF = NB <= 12 ? 3 : 1;
+        dist_rounds_inflight<NB, RS, TAIL, RIF, true, 24>(ix, natural_view(q, NB), pids, dists, na, 8 * (wv - 1));
+    } else {
+        dist_rounds_inflight_rt<8, 2, 24>(ix, natural_view(q, (int)ix.nb), pids, dists, na, 8 * (wv - 1));
+    }
+}
+template <int NB, int RS, int TAIL, int LAT>
+__device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const float* q, QuadCtl* ctl, const uint32_t* act_pid,
+                                                 uint32_t* act_dist, int wv, const Visited& vis) {
+    const int lane = lane_id();
     for (;;) {
-        block_sync();                                                  // B1
-        const uint32_t na = uniform_u32(ctl->na);
-        if (na == kQuadExit) break;
-        dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, (int)na, wv);
-        block_sync();                                                  // B2
+        block_sync();                                                  // A
+        const uint32_t cmd = uniform_u32(ctl->cmd);
+        if (cmd == kQuadExit) break;
+        if (cmd == kQuadPass) {
+            dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, (int)uniform_u32(ctl->na), wv);
+            block_sync();                                              // B
+        } else if (cmd == kQuadSpec) {
+            const uint32_t id = ctl->spec_row[lane];
+            const uint64_t inval = __ballot(id == kInvalid);
+            const int nv = inval ? __builtin_ctzll(inval) : 64;
+            bool fresh = false, other = false;                         // other: only the bitmap knows
+            if (lane < nv && id < ix.n) {
+                if constexpr (walk_vis16(LAT)) {
+                    const int st = q16_lookup(vis, id);
+                    fresh = st == kQRoom;
+                    other = st == kQFull;
+                } else {
+                    fresh = !tab_find(vis, id);
+                }
+            }
+            if (__ballot(other)) {
+                if (wv == 1 && lane == 0) ctl->spec_n = kSpecAbort;
+                continue;
+            }
+            const uint64_t fm = __ballot(fresh);
+            if (fresh) ctl->spec_new[__popcll(fm & ((1ull << lane) - 1ull))] = id;   // (the same values from all three helpers)
+            if (wv == 1 && lane == 0) ctl->spec_n = (uint32_t)__popcll(fm);
+            wave_sync();
+            dist_rounds_spec<NB, RS, TAIL>(ix, q, ctl->spec_new, ctl->spec_dist, __popcll(fm), wv);
+        }
     }
 }
 __device__ __forceinline__ void quad_release_helpers(QuadCtl* ctl) {
-    if (lane_id() == 0) ctl->na = kQuadExit;
-    block_sync();                                                      // B1 of the helpers' last iteration
+    if (lane_id() == 0) ctl->cmd = kQuadExit;
+    block_sync();                                                      // A of the helpers' last iteration
 }
 
 // Search::push for the very first entry point (core/lib.rs:364, :444)
@@ -1405,6 +1473,10 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     // visited test-and-set in flight during the first distance pass (bitmap + Bloom filter only: the on-chip set answers at once)
     constexpr bool OVL = walk_mode(LAT) != kWalkClassic && !walk_vis_lds(LAT);
     uint32_t pf_pid = kInvalid, pf_row = kInvalid;
+    // four-wave walk with the visited set on chip: the helpers work one expansion ahead (QuadCtl)
+    constexpr bool kSpec = walk_quad(LAT) && walk_vis_lds(LAT) && PFA;
+    [[maybe_unused]] uint32_t sq_pid = kInvalid;          // the candidate whose row the helpers were given (wave-uniform)
+    [[maybe_unused]] bool sq_off = false;                 // this layer met an id only the bitmap answers for: no more guesses
     for (;;) {
         int ci = w_pop(st);                               // :599-604
         if (ci < 0 && st.spill_n && w_refill_ties(st)) ci = w_pop(st);   // live ties that did not fit the LDS region
@@ -1431,25 +1503,62 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         const int nvalid = inval ? __builtin_ctzll(inval) : 64;
         const bool is_nb = lane < nvalid;
 
-        if constexpr (walk_vis16(LAT)) {
+        // What the branches below hand to the common tail: this lane's key (slot order = lane order), whether it is a new id,
+        // how many there are, and (build) where the id sits in the on-chip set.
+        uint64_t key = kMaxKey;
+        bool fresh = false;
+        int na = 0, tab_idx = -1;
+        uint32_t my_d = 0, my_id = nb_pid;
+        if (is_nb && nb_pid >= ix.n) st.status |= kStBadRow;
+        const bool ok_nb = is_nb && nb_pid < ix.n;
+
+        // four-wave walk: did the helpers work this expansion out in advance (QuadCtl)?
+        [[maybe_unused]] bool took = false;
+        if constexpr (kSpec) {
+            if (sq_pid != kInvalid && sq_pid == cpid) {
+                const uint32_t ns = quad_take_spec(quad);
+                if (ns != kSpecAbort) {
+                    took = true;
+                    na = (int)ns;
+                    fresh = lane < na;
+                    my_id = fresh ? quad->spec_new[lane] : kInvalid;
+                    my_d = fresh ? quad->spec_dist[lane] : 0u;
+                    // the inserts a distance pass would have made while its rows were in flight
+                    if constexpr (walk_vis16(LAT)) {
+                        if (fresh && q16_insert(vis, my_id, tab_idx) == kQFull) {       // filled up by this very expansion
+                            atomicOr(&vis.bits[my_id >> 5], 1u << (my_id & 31u));
+                            visited_note(vis, my_id);
+                        }
+                    } else {
+                        visited_begin(vis);
+                        if (fresh) tab_idx = tab_insert(vis, my_id);
+                        visited_added(vis, (uint32_t)na);
+                    }
+                } else {
+                    sq_off = true;                                    // an id of the bitmap class: no more guesses on this layer
+                }
+            }
+            sq_pid = kInvalid;
+        }
+
+        if (took) {
+            // (nothing: ids and distances came from the helpers)
+        } else if constexpr (walk_vis16(LAT)) {
             // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40, on the quotient set: one LDS round trip tells
             // every neighbour apart — known / surely new (a home bucket has room: it never went to the bitmap) / both
             // home buckets full (the bitmap decides).  The surely new ones go to the distance pass at once and enter the
             // set while their rows are in flight; the test-and-set of the others is in flight during that pass, and
             // those that turn out new get a second pass.  Keys are pushed in slot order afterwards, whichever pass
             // computed them.
-            int stt = kQFound, tab_idx = -1;
+            int stt = kQFound;
             uint32_t vold = 0;
             const uint32_t vbit = 1u << (nb_pid & 31u);
-            if (is_nb) {
-                if (nb_pid >= ix.n) st.status |= kStBadRow;
-                else {
-                    stt = q16_lookup(vis, nb_pid);
-                    if (stt == kQFull) vold = atomicOr(&vis.bits[nb_pid >> 5], vbit);
-                }
+            if (ok_nb) {
+                stt = q16_lookup(vis, nb_pid);
+                if (stt == kQFull) vold = atomicOr(&vis.bits[nb_pid >> 5], vbit);
             }
-            const bool sure = is_nb && stt == kQRoom, maybe = is_nb && stt == kQFull;
-            uint32_t my_d = 0;
+            const bool sure = ok_nb && stt == kQRoom, maybe = ok_nb && stt == kQFull;
+            if constexpr (kSpec) { if (__ballot(maybe)) sq_off = true; }
             const uint64_t sm = __ballot(sure);
             wave_sync();
             if (sm) {
@@ -1480,31 +1589,21 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 wave_sync();
                 if (late) my_d = act_dist[my];
             }
-            const bool fresh = sure || late;
-            const int na = __popcll(sm) + __popcll(lm);
-            if (na) {
-                ctr.n_dist += (uint32_t)na;
-                uint64_t key = kMaxKey;
-                if (fresh) key = ((uint64_t)my_d << 32) | nb_pid;
-                if (dlog.log) dlog_append(dlog, fresh ? tab_idx : -1, my_d);            // (ids that went to the bitmap have no index)
-                w_push_keys<push_chunks<LAT>()>(st, key, fresh);
-            }
+            fresh = sure || late;                                                       // (ids that went to the bitmap have no index)
+            na = __popcll(sm) + __popcll(lm);
         } else if constexpr (!OVL) {
             // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40
-            bool fresh = false;
-            int tab_idx = -1;
             visited_begin(vis);
             // While the on-chip set takes new ids, an expansion only LOOKS its neighbours up here; the new ones are
             // inserted while their rows are in flight (`mid` below) — rows never hold duplicates (validated on import,
             // impossible in a built graph), so "not in the set" is final.  Every other configuration inserts at once.
             const bool defer = vis.tab != nullptr && !vis.spill;
-            if (is_nb) {
-                if (nb_pid >= ix.n) st.status |= kStBadRow;
-                else if (defer) fresh = !tab_find(vis, nb_pid);
+            if (ok_nb) {
+                if (defer) fresh = !tab_find(vis, nb_pid);
                 else fresh = visited_insert(vis, nb_pid, tab_idx);
             }
             const uint64_t fm = __ballot(fresh);
-            const int na = __popcll(fm);
+            na = __popcll(fm);
             visited_added(vis, (uint32_t)na);
             wave_sync();
             if (na) {
@@ -1518,23 +1617,17 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, na, mid);
                 else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na, mid, thr_bits);     // :709-710
                 wave_sync();
-                ctr.n_dist += (uint32_t)na;
-                uint64_t key = kMaxKey;
-                if (fresh) key = ((uint64_t)act_dist[my] << 32) | nb_pid;
-                if (dlog.log) dlog_append(dlog, fresh ? tab_idx : -1, (uint32_t)(key >> 32));
-                w_push_keys<push_chunks<LAT>()>(st, key, fresh);
+                if (fresh) my_d = act_dist[my];
             }
         } else {
             bool sure = false, maybe = false;
             uint32_t vold = 0;
             const uint32_t vbit = 1u << (nb_pid & 31u);
-            if (is_nb) {
-                if (nb_pid >= ix.n) st.status |= kStBadRow;
-                else if (vis.bloom && !bloom_maybe(vis, nb_pid)) sure = true;
+            if (ok_nb) {
+                if (vis.bloom && !bloom_maybe(vis, nb_pid)) sure = true;
                 else { maybe = true; vold = atomicOr(&vis.bits[nb_pid >> 5], vbit); }   // test-and-set, in flight during the first pass
             }
             if (sure) visited_mark(vis, nb_pid);
-            uint32_t my_d = 0;
             const uint64_t sm = __ballot(sure);
             wave_sync();
             if (sm) {
@@ -1557,15 +1650,26 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 wave_sync();
                 if (late) my_d = act_dist[my];
             }
-            const bool fresh = sure || late;
-            const int na = __popcll(sm) + __popcll(lm);
-            if (na) {
-                ctr.n_dist += (uint32_t)na;
-                uint64_t key = kMaxKey;
-                if (fresh) key = ((uint64_t)my_d << 32) | nb_pid;
-                if (dlog.log) dlog_append(dlog, fresh ? vis_index(vis, nb_pid) : -1, my_d);
-                w_push_keys<push_chunks<LAT>()>(st, key, fresh);
+            fresh = sure || late;
+            na = __popcll(sm) + __popcll(lm);
+            if (dlog.log && fresh) tab_idx = vis_index(vis, nb_pid);
+        }
+
+        // four-wave walk: hand the row of the candidate expected next to the helpers — they work on it while this wave pushes
+        if constexpr (kSpec) {
+            bool ask = !sq_off && pf_pid != kInvalid;
+            if constexpr (!walk_vis16(LAT)) ask = ask && vis.tab != nullptr && !vis.spill && vis.count + 128u <= vis.tlimit;
+            if (ask) {
+                quad_post_spec(quad, pf_row);
+                sq_pid = pf_pid;
             }
+        }
+
+        if (na) {                                                                       // Search::push in slot order, :606-608
+            ctr.n_dist += (uint32_t)na;
+            if (fresh) key = ((uint64_t)my_d << 32) | my_id;
+            if (dlog.log) dlog_append(dlog, fresh ? tab_idx : -1, my_d);
+            w_push_keys<push_chunks<LAT>()>(st, key, fresh);
         }
         w_truncate(st);                                    // :612
         if (++guard > ix.n + 64u) { st.status |= kStGuard; break; }

@@ -91,7 +91,7 @@ struct Smem {
     uint64_t* aux;       // 3*64+1 u64 (build only): news / sel / disc
     uint32_t* act_pid;   // 64
     uint32_t* act_dist;  // 64
-    QuadCtl* ctl;        // hand-over word of the four-wave walk (16 B)
+    QuadCtl* ctl;        // hand-over block of the four-wave walk: command words + the speculated row, its new ids, their distances
     uint32_t* dirty;     // dirty-block bitmap of the visited set (graph walks only), dirty_words dwords
     uint32_t* bloom;     // kBloomWords / kBloomLatWords, last in the carve-up (graph walks only)
 };
@@ -188,17 +188,17 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
     const Smem sm = carve(smem_raw, ix.stride, a.wcap, false, a.vis.dirty_words);
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
-    if constexpr (walk_quad(LAT)) {
-        const int wv = (int)uniform_u32(threadIdx.x >> 6);
-        if (wv != 0) {
-            quad_helper_loop<NB, RS, TAIL>(ix, sm.q, sm.ctl, sm.act_pid, sm.act_dist, wv);
-            return;
-        }
-    }
     Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words,
                 a.use_bloom ? sm.bloom : nullptr, walk_mode(LAT) == kWalkLatency ? kBloomLatLog2Words : kBloomLog2Words};
     if constexpr (walk_vis_lds(LAT)) visited_attach_tab(vis, sm.bloom, a.tab_log2);
     if constexpr (walk_vis16(LAT)) visited_attach_q16(vis, a.tab_log2, a.ubits);
+    if constexpr (walk_quad(LAT)) {
+        const int wv = (int)uniform_u32(threadIdx.x >> 6);
+        if (wv != 0) {                                                 // (the helpers only ever READ the on-chip set through `vis`)
+            quad_helper_loop<NB, RS, TAIL, LAT>(ix, sm.q, sm.ctl, sm.act_pid, sm.act_dist, wv, vis);
+            return;
+        }
+    }
     uint32_t status = 0;
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
     for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
@@ -500,16 +500,16 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
     uint64_t* sel = sm.aux + 64 + 8;
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
-    if constexpr (walk_quad(LAT)) {
-        const int wv = (int)uniform_u32(threadIdx.x >> 6);
-        if (wv != 0) {
-            quad_helper_loop<NB, RS, TAIL>(ix, sm.q, sm.ctl, sm.act_pid, sm.act_dist, wv);
-            return;
-        }
-    }
     Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words, nullptr, 0};
     visited_attach_tab(vis, sm.bloom, a.tab_log2);                    // the descent always keeps its visited set on chip
     if constexpr (walk_vis16(LAT)) visited_attach_q16(vis, a.tab_log2, a.ubits);
+    if constexpr (walk_quad(LAT)) {
+        const int wv = (int)uniform_u32(threadIdx.x >> 6);
+        if (wv != 0) {                                                 // (the helpers only ever READ the on-chip set through `vis`)
+            quad_helper_loop<NB, RS, TAIL, LAT>(ix, sm.q, sm.ctl, sm.act_pid, sm.act_dist, wv, vis);
+            return;
+        }
+    }
     uint32_t status = 0;
     Counters tot{0, 0, 0};
     for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
