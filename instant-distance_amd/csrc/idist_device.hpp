@@ -1254,35 +1254,45 @@ struct Counters {
 //     kQuadExit      helpers leave
 enum : uint32_t { kQuadPass = 0, kQuadSpec = 1, kQuadTake = 2, kQuadExit = 3 };
 constexpr uint32_t kSpecAbort = 0xFFFFFFFFu;            // spec_n: the row holds an id only the bitmap can answer for
+// The command word and the row count are kept TWICE, by the parity of the barrier they belong to: after barrier k the helpers
+// read cmd[k & 1] while the leader may already be writing cmd[(k + 1) & 1] for its next command (nothing but that barrier
+// stands between "the helpers were released" and "the leader posts again").  Every wave counts the A barriers it passed.
 struct QuadCtl {
-    uint32_t cmd, na, spec_n, pad;
+    uint32_t cmd[2], na[2], spec_n, pad[3];
     uint32_t spec_row[64];                               // leader -> helpers: the predicted candidate's adjacency row (slot order)
     uint32_t spec_new[64];                               // helpers -> leader: its new ids, compacted in slot order
     uint32_t spec_dist[64];                              // ... and their canonical distance bits
 };
+// the leader's end of the protocol: the control block and the number of A barriers passed so far (wave-uniform, in registers)
+struct QuadLead {
+    QuadCtl* ctl = nullptr;
+    uint32_t seq = 0;
+    __device__ __forceinline__ void post(uint32_t cmd, uint32_t na = 0u) {
+        if (lane_id() == 0) { ctl->cmd[seq & 1u] = cmd; ctl->na[seq & 1u] = na; }
+        block_sync();                                                  // A
+        seq++;
+    }
+};
 template <int NB, int RS, int TAIL, class Mid = NoMid>
-__device__ __forceinline__ void quad_dist_pass(const IndexView& ix, const float* q, QuadCtl* ctl, const uint32_t* act_pid,
+__device__ __forceinline__ void quad_dist_pass(const IndexView& ix, const float* q, QuadLead& ql, const uint32_t* act_pid,
                                                uint32_t* act_dist, int na, Mid mid = Mid()) {
     if (na <= 8) {                                                     // a single round: not worth two barriers
         dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0, mid);
         return;
     }
-    if (lane_id() == 0) { ctl->cmd = kQuadPass; ctl->na = (uint32_t)na; }
-    block_sync();                                                      // A
+    ql.post(kQuadPass, (uint32_t)na);
     dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0, mid);
     block_sync();                                                      // B
 }
 // leader: hand the predicted candidate's row to the helpers (row_id: this lane's slot of it, kInvalid beyond its end)
-__device__ __forceinline__ void quad_post_spec(QuadCtl* ctl, uint32_t row_id) {
-    ctl->spec_row[lane_id()] = row_id;
-    if (lane_id() == 0) ctl->cmd = kQuadSpec;
-    block_sync();                                                      // A
+__device__ __forceinline__ void quad_post_spec(QuadLead& ql, uint32_t row_id) {
+    ql.ctl->spec_row[lane_id()] = row_id;
+    ql.post(kQuadSpec);
 }
 // leader: wait for the speculation it asked for; number of new ids in ctl->spec_new / spec_dist, or kSpecAbort
-__device__ __forceinline__ uint32_t quad_take_spec(QuadCtl* ctl) {
-    if (lane_id() == 0) ctl->cmd = kQuadTake;
-    block_sync();                                                      // A: the helpers arrive when they are done
-    return uniform_u32(ctl->spec_n);
+__device__ __forceinline__ uint32_t quad_take_spec(QuadLead& ql) {
+    ql.post(kQuadTake);                                                // the helpers arrive at A when they are done
+    return uniform_u32(ql.ctl->spec_n);
 }
 // the helpers' three-way split of a speculated list: wave wv (1..3) takes rounds wv - 1, wv + 2, ... of 8 rows
 template <int NB, int RS, int TAIL>
@@ -1298,12 +1308,12 @@ template <int NB, int RS, int TAIL, int LAT>
 __device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const float* q, QuadCtl* ctl, const uint32_t* act_pid,
                                                  uint32_t* act_dist, int wv, const Visited& vis) {
     const int lane = lane_id();
-    for (;;) {
-        block_sync();                                                  // A
-        const uint32_t cmd = uniform_u32(ctl->cmd);
+    for (uint32_t seq = 0;; seq++) {
+        block_sync();                                                  // A number `seq`
+        const uint32_t cmd = uniform_u32(ctl->cmd[seq & 1u]);
         if (cmd == kQuadExit) break;
         if (cmd == kQuadPass) {
-            dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, (int)uniform_u32(ctl->na), wv);
+            dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, (int)uniform_u32(ctl->na[seq & 1u]), wv);
             block_sync();                                              // B
         } else if (cmd == kQuadSpec) {
             const uint32_t id = ctl->spec_row[lane];
@@ -1331,10 +1341,7 @@ __device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const floa
         }
     }
 }
-__device__ __forceinline__ void quad_release_helpers(QuadCtl* ctl) {
-    if (lane_id() == 0) ctl->cmd = kQuadExit;
-    block_sync();                                                      // A of the helpers' last iteration
-}
+__device__ __forceinline__ void quad_release_helpers(QuadLead& ql) { ql.post(kQuadExit); }   // A of the helpers' last iteration
 
 // Search::push for the very first entry point (core/lib.rs:364, :444)
 template <int NB, int RS, int TAIL>
@@ -1465,7 +1472,7 @@ template <int NB, int RS, int TAIL, int LAT = 0>
 __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t* rows, int row_stride, int links,
                                              const float* q, WState& st, Visited& vis, uint32_t* act_pid,
                                              uint32_t* act_dist, Counters& ctr, bool is_zero, DistLog& dlog,
-                                             QuadCtl* quad = nullptr) {
+                                             QuadLead* quad = nullptr) {
     const int lane = lane_id();
     uint32_t guard = 0;
     const bool row_lane = lane < row_stride && lane < links;
@@ -1475,6 +1482,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     uint32_t pf_pid = kInvalid, pf_row = kInvalid;
     // four-wave walk with the visited set on chip: the helpers work one expansion ahead (QuadCtl)
     constexpr bool kSpec = walk_quad(LAT) && walk_vis_lds(LAT) && PFA;
+    [[maybe_unused]] uint32_t pf2_pid = kInvalid, pf2_row = kInvalid;   // adjacency requested two expansions ahead
     [[maybe_unused]] uint32_t sq_pid = kInvalid;          // the candidate whose row the helpers were given (wave-uniform)
     [[maybe_unused]] bool sq_off = false;                 // this layer met an id only the bitmap answers for: no more guesses
     for (;;) {
@@ -1489,7 +1497,31 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
 
         // layer.nearest_iter(pid).take(links): stop at first INVALID (core/types.rs:183-187)
         uint32_t nb_pid = kInvalid;
-        if constexpr (PFA) {
+        if constexpr (kSpec) {
+            // The helpers need the NEXT candidate's row while this expansion still runs, i.e. an expansion earlier than the
+            // walk itself does: adjacency rows are requested TWO expansions ahead (pf2: the candidate expected after the next
+            // one), so that the row handed to the helpers has had a whole expansion to arrive.
+            if (cpid == pf_pid) nb_pid = pf_row;
+            else if (cpid == pf2_pid) nb_pid = pf2_row;
+            else if (row_lane) nb_pid = rows[(size_t)cpid * row_stride + lane];
+            const int c2 = w_peek_next(st, ci);
+            const uint32_t n_pid = c2 >= 0 ? (uint32_t)st.W[c2] : kInvalid;
+            uint32_t n_row = kInvalid;
+            if (n_pid != kInvalid) {
+                if (n_pid == pf2_pid) n_row = pf2_row;                                   // (the usual case: asked for last time)
+                else if (n_pid == pf_pid) n_row = pf_row;
+                else if (row_lane) n_row = rows[(size_t)n_pid * row_stride + lane];
+            }
+            const int c3 = c2 >= 0 ? w_peek_next(st, c2) : -1;
+            const uint32_t m_pid = c3 >= 0 ? (uint32_t)st.W[c3] : kInvalid;
+            uint32_t m_row = kInvalid;
+            if (m_pid != kInvalid) {
+                if (m_pid == pf2_pid) m_row = pf2_row;
+                else if (row_lane) m_row = rows[(size_t)m_pid * row_stride + lane];
+            }
+            pf_pid = n_pid; pf_row = n_row;
+            pf2_pid = m_pid; pf2_row = m_row;
+        } else if constexpr (PFA) {
             if (cpid == pf_pid) nb_pid = pf_row;
             else if (row_lane) nb_pid = rows[(size_t)cpid * row_stride + lane];
             const int c2 = w_peek_next(st, ci);
@@ -1516,13 +1548,13 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         [[maybe_unused]] bool took = false;
         if constexpr (kSpec) {
             if (sq_pid != kInvalid && sq_pid == cpid) {
-                const uint32_t ns = quad_take_spec(quad);
+                const uint32_t ns = quad_take_spec(*quad);
                 if (ns != kSpecAbort) {
                     took = true;
                     na = (int)ns;
                     fresh = lane < na;
-                    my_id = fresh ? quad->spec_new[lane] : kInvalid;
-                    my_d = fresh ? quad->spec_dist[lane] : 0u;
+                    my_id = fresh ? quad->ctl->spec_new[lane] : kInvalid;
+                    my_d = fresh ? quad->ctl->spec_dist[lane] : 0u;
                     // the inserts a distance pass would have made while its rows were in flight
                     if constexpr (walk_vis16(LAT)) {
                         if (fresh && q16_insert(vis, my_id, tab_idx) == kQFull) {       // filled up by this very expansion
@@ -1571,7 +1603,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                         visited_note(vis, nb_pid);
                     }
                 };
-                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, __popcll(sm), mid);
+                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, *quad, act_pid, act_dist, __popcll(sm), mid);
                 else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, __popcll(sm), mid);
                 wave_sync();
                 if (sure) my_d = act_dist[my];
@@ -1584,7 +1616,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 const int my = __popcll(lm & ((1ull << lane) - 1ull));
                 if (late) act_pid[my] = nb_pid;
                 wave_sync();
-                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, __popcll(lm));
+                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, *quad, act_pid, act_dist, __popcll(lm));
                 else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, __popcll(lm));
                 wave_sync();
                 if (late) my_d = act_dist[my];
@@ -1614,7 +1646,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 // early abandon (measurement builds): the furthest distance of a full `nearest` as this expansion begins
                 [[maybe_unused]] uint32_t thr_bits = 0xFFFFFFFFu;
                 if constexpr (walk_ea(LAT) > 0) { if (st.plen >= st.ef && !dlog.log) thr_bits = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32); }
-                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, quad, act_pid, act_dist, na, mid);
+                if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, *quad, act_pid, act_dist, na, mid);
                 else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na, mid, thr_bits);     // :709-710
                 wave_sync();
                 if (fresh) my_d = act_dist[my];
@@ -1660,7 +1692,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             bool ask = !sq_off && pf_pid != kInvalid;
             if constexpr (!walk_vis16(LAT)) ask = ask && vis.tab != nullptr && !vis.spill && vis.count + 128u <= vis.tlimit;
             if (ask) {
-                quad_post_spec(quad, pf_row);
+                quad_post_spec(*quad, pf_row);
                 sq_pid = pf_pid;
             }
         }

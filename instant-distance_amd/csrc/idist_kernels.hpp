@@ -200,6 +200,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         }
     }
     uint32_t status = 0;
+    QuadLead ql{sm.ctl, 0u};                                           // (four-wave walk: this wave leads)
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
     for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
     visited_clear(vis);                                                // LDS side; the slot's bitmap is clean between launches
@@ -232,11 +233,11 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
             const bool is_zero = cur == 0;
             st.ef = is_zero ? (int)a.ef : 1;                           // :366-371
             if (is_zero) {
-                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true, nolog, sm.ctl);
+                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true, nolog, &ql);
                 break;
             }
             const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false, nolog, sm.ctl);
+            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false, nolog, &ql);
             w_cull(st);                                                // :377-379
             visited_clear(vis);
             visited_begin(vis, (uint32_t)st.plen);
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         status |= st.status;
         visited_clear(vis);                                            // leave the slot empty for its next search
     }
-    if constexpr (walk_quad(LAT)) quad_release_helpers(sm.ctl);
+    if constexpr (walk_quad(LAT)) quad_release_helpers(ql);
     if (lane == 0 && status) {
         atomicOr(a.status, status);
         if (a.status_host) a.status_host[blockIdx.x] = status;
@@ -455,7 +456,7 @@ __device__ __forceinline__ void emit_new_node(const IndexView& ix, const BuildAr
 // the insertion layer's visited set in `vis`.
 template <int NB, int RS, int TAIL, int LAT>
 __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildArgs& a, const Smem& sm, WState& st, Visited& vis,
-                                               uint32_t nw_pid, Counters& tot, DistLog& dl) {
+                                               uint32_t nw_pid, Counters& tot, DistLog& dl, QuadLead* ql = nullptr) {
     const int lane = lane_id();
     wave_sync();
     // point = &points[new] (:442): rows are stored blocked already
@@ -470,7 +471,7 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
         st.ef = cur <= (int)a.layer ? (int)a.efc : 1;             // :448-452
         if (cur > (int)a.layer) {                                 // :453-457
             const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dl, walk_quad(LAT) ? sm.ctl : nullptr);
+            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dl, ql);
             w_cull(st);
             visited_clear(vis);
             visited_begin(vis, (uint32_t)st.plen);
@@ -485,7 +486,7 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
                     dlog_append(dl, on ? vis_index(vis, (uint32_t)k) : -1, (uint32_t)(k >> 32));
                 }
         } else {                                                  // :458-461
-            search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dl, walk_quad(LAT) ? sm.ctl : nullptr);
+            search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dl, ql);
             break;
         }
     }
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         }
     }
     uint32_t status = 0;
+    QuadLead ql{sm.ctl, 0u};                                          // (four-wave descents: this wave leads)
     Counters tot{0, 0, 0};
     for (uint32_t i = lane; i < a.vis.dirty_words; i += 64) sm.dirty[i] = 0u;
     visited_clear(vis);                                               // LDS side; the slot's bitmap is clean between launches
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         // only the heuristic's re-selections look distances up
         DistLog dl{a.has_heuristic && a.use_dlog ? a.dlog_log + ((size_t)item << a.dl_shift) : nullptr, 0u};
         if constexpr (walk_vis16(LAT)) dl.half = 4u << (a.tab_log2 - 2u);     // dwords of the set = entries of one half
-        insert_descent<NB, RS, TAIL, LAT>(ix, a, sm, st, vis, nw_pid, tot, dl);
+        insert_descent<NB, RS, TAIL, LAT>(ix, a, sm, st, vis, nw_pid, tot, dl, walk_quad(LAT) ? &ql : nullptr);
         const int nw = st.plen < st.ef ? st.plen : st.ef;             // Search.nearest
         // (the hand-over addresses below depend on nothing but the item: hipcc computed them up here and kept them in
         // scratch across the whole walk — an opaque copy of the item pins their computation to where they are used)
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         status |= st.status;
         visited_clear(vis);                                           // leave the slot empty for its next descent
     }
-    if constexpr (walk_quad(LAT)) quad_release_helpers(sm.ctl);
+    if constexpr (walk_quad(LAT)) quad_release_helpers(ql);
     if (lane == 0) {
         if (status) atomicOr(a.status, status);
         if (tot.n_dist | tot.n_exp0 | tot.n_expU) {
