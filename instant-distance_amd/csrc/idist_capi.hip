@@ -883,6 +883,19 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     return device_status_to_code(small[6], cfg.tie_policy);
 }
 
+#ifdef IDIST_PROBE
+// measurement build: the four-wave walk's segment ticks (g_quad_probe, idist_device.hpp); reset != 0 clears them after the read
+extern "C" int idist_probe_quad(unsigned long long* out24, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_quad_probe), 24 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[24] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_quad_probe), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#endif
+
 idist_status build_common(const void* points, bool on_device, uint32_t n, uint32_t dim, const idist_config* cfg,
                           int32_t device, idist_index** out) {
     CHK(validate_config(cfg, true));

@@ -1252,13 +1252,27 @@ struct Counters {
 //     kQuadSpec      helpers: speculate on ctl->spec_row (the row of ctl->spec_pid)
 //     kQuadTake      nothing — the barrier itself is the hand-over: helpers arrive at A when their speculation is done
 //     kQuadExit      helpers leave
+// Measurement build (make probe): where the leader of a four-wave walk and its helpers spend a zero-layer walk — 10-ns ticks
+// per segment, summed over all walks since the last reset (idist_probe_quad in idist_capi.hip).
+#ifdef IDIST_PROBE
+__device__ unsigned long long g_quad_probe[24];
+#define QP_DECL unsigned long long qp[12] = {}; unsigned long long qp_t = wall_clock64();
+#define QP_MARK(i) { const unsigned long long t_ = wall_clock64(); qp[i] += t_ - qp_t; qp_t = t_; }
+#define QP_CNT(i, v) { qp[i] += (unsigned long long)(v); }
+#define QP_FLUSH(on) { if ((on) && lane_id() == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_quad_probe[i_], qp[i_]); }
+#else
+#define QP_DECL
+#define QP_MARK(i)
+#define QP_CNT(i, v)
+#define QP_FLUSH(on)
+#endif
 enum : uint32_t { kQuadPass = 0, kQuadSpec = 1, kQuadTake = 2, kQuadExit = 3 };
 constexpr uint32_t kSpecAbort = 0xFFFFFFFFu;            // spec_n: the row holds an id only the bitmap can answer for
 // The command word and the row count are kept TWICE, by the parity of the barrier they belong to: after barrier k the helpers
 // read cmd[k & 1] while the leader may already be writing cmd[(k + 1) & 1] for its next command (nothing but that barrier
 // stands between "the helpers were released" and "the leader posts again").  Every wave counts the A barriers it passed.
 struct QuadCtl {
-    uint32_t cmd[2], na[2], spec_n, pad[3];
+    uint32_t cmd[2], na[2], spec_n, commit_n, pad[2];     // commit_n: ids of the previous guess still on their way into the set (list in act_dist)
     uint32_t spec_row[64];                               // leader -> helpers: the predicted candidate's adjacency row (slot order)
     uint32_t spec_new[64];                               // helpers -> leader: its new ids, compacted in slot order
     uint32_t spec_dist[64];                              // ... and their canonical distance bits
@@ -1285,8 +1299,13 @@ __device__ __forceinline__ void quad_dist_pass(const IndexView& ix, const float*
     block_sync();                                                      // B
 }
 // leader: hand the predicted candidate's row to the helpers (row_id: this lane's slot of it, kInvalid beyond its end)
-__device__ __forceinline__ void quad_post_spec(QuadLead& ql, uint32_t row_id) {
+// pending (id set only): the ids the leader took from the previous guess and inserts into the set AFTER this hand-over, i.e.
+// while the helpers look the new row up — they count as visited.  The list travels in act_dist (nobody writes it before the
+// next shared pass, and the helpers reach that pass's barrier only when they are done here).
+__device__ __forceinline__ void quad_post_spec(QuadLead& ql, uint32_t row_id, uint32_t* act_dist, uint32_t pending_id, uint32_t n_pending) {
     ql.ctl->spec_row[lane_id()] = row_id;
+    if (n_pending) act_dist[lane_id()] = pending_id;
+    if (lane_id() == 0) ql.ctl->commit_n = n_pending;
     ql.post(kQuadSpec);
 }
 // leader: wait for the speculation it asked for; number of new ids in ctl->spec_new / spec_dist, or kSpecAbort
@@ -1316,6 +1335,9 @@ __device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const floa
             dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, (int)uniform_u32(ctl->na[seq & 1u]), wv);
             block_sync();                                              // B
         } else if (cmd == kQuadSpec) {
+#ifdef IDIST_PROBE
+            const unsigned long long hp0 = wall_clock64();
+#endif
             const uint32_t id = ctl->spec_row[lane];
             const uint64_t inval = __ballot(id == kInvalid);
             const int nv = inval ? __builtin_ctzll(inval) : 64;
@@ -1327,6 +1349,12 @@ __device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const floa
                     other = st == kQFull;
                 } else {
                     fresh = !tab_find(vis, id);
+                    const uint32_t cn = uniform_u32(ctl->commit_n);             // (see quad_post_spec)
+                    const uint4* c4 = reinterpret_cast<const uint4*>(act_dist);
+                    for (uint32_t j = 0; 4u * j < cn; j++) {
+                        const uint4 c = c4[j];
+                        if (id == c.x || id == c.y || id == c.z || id == c.w) fresh = false;
+                    }
                 }
             }
             if (__ballot(other)) {
@@ -1337,7 +1365,18 @@ __device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const floa
             if (fresh) ctl->spec_new[__popcll(fm & ((1ull << lane) - 1ull))] = id;   // (the same values from all three helpers)
             if (wv == 1 && lane == 0) ctl->spec_n = (uint32_t)__popcll(fm);
             wave_sync();
+#ifdef IDIST_PROBE
+            const unsigned long long hp1 = wall_clock64();
+#endif
             dist_rounds_spec<NB, RS, TAIL>(ix, q, ctl->spec_new, ctl->spec_dist, __popcll(fm), wv);
+#ifdef IDIST_PROBE
+            if (lane == 0) {
+                const unsigned long long hp2 = wall_clock64();
+                atomicAdd(&g_quad_probe[12 + 3 * (wv - 1)], hp1 - hp0);
+                atomicAdd(&g_quad_probe[13 + 3 * (wv - 1)], hp2 - hp1);
+                atomicAdd(&g_quad_probe[14 + 3 * (wv - 1)], 1ull);
+            }
+#endif
         }
     }
 }
@@ -1483,8 +1522,10 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     // four-wave walk with the visited set on chip: the helpers work one expansion ahead (QuadCtl)
     constexpr bool kSpec = walk_quad(LAT) && walk_vis_lds(LAT) && PFA;
     [[maybe_unused]] uint32_t pf2_pid = kInvalid, pf2_row = kInvalid;   // adjacency requested two expansions ahead
+    [[maybe_unused]] uint64_t pk_key = ~0ull;             // key of the first old un-expanded entry behind the current candidate
     [[maybe_unused]] uint32_t sq_pid = kInvalid;          // the candidate whose row the helpers were given (wave-uniform)
     [[maybe_unused]] bool sq_off = false;                 // this layer met an id only the bitmap answers for: no more guesses
+    QP_DECL
     for (;;) {
         int ci = w_pop(st);                               // :599-604
         if (ci < 0 && st.spill_n && w_refill_ties(st)) ci = w_pop(st);   // live ties that did not fit the LDS region
@@ -1494,6 +1535,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         if (lane == 0) st.W[ci] = c | kFlag;
         const uint32_t cpid = (uint32_t)c;
         if (is_zero) ctr.n_exp0++; else ctr.n_expU++;
+        QP_MARK(0) QP_CNT(6, 1)
 
         // layer.nearest_iter(pid).take(links): stop at first INVALID (core/types.rs:183-187)
         uint32_t nb_pid = kInvalid;
@@ -1505,6 +1547,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             else if (cpid == pf2_pid) nb_pid = pf2_row;
             else if (row_lane) nb_pid = rows[(size_t)cpid * row_stride + lane];
             const int c2 = w_peek_next(st, ci);
+            pk_key = c2 >= 0 ? (st.W[c2] & kKeyMask) : ~0ull;
             const uint32_t n_pid = c2 >= 0 ? (uint32_t)st.W[c2] : kInvalid;
             uint32_t n_row = kInvalid;
             if (n_pid != kInvalid) {
@@ -1546,10 +1589,13 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
 
         // four-wave walk: did the helpers work this expansion out in advance (QuadCtl)?
         [[maybe_unused]] bool took = false;
+        QP_MARK(1)
         if constexpr (kSpec) {
             if (sq_pid != kInvalid && sq_pid == cpid) {
                 const uint32_t ns = quad_take_spec(*quad);
+                QP_MARK(2)
                 if (ns != kSpecAbort) {
+                    QP_CNT(7, 1)
                     took = true;
                     na = (int)ns;
                     fresh = lane < na;
@@ -1561,17 +1607,15 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                             atomicOr(&vis.bits[my_id >> 5], 1u << (my_id & 31u));
                             visited_note(vis, my_id);
                         }
-                    } else {
-                        visited_begin(vis);
-                        if (fresh) tab_idx = tab_insert(vis, my_id);
-                        visited_added(vis, (uint32_t)na);
-                    }
+                    }                                                 // (id set: inserted below, behind the next hand-over)
                 } else {
                     sq_off = true;                                    // an id of the bitmap class: no more guesses on this layer
+                    QP_CNT(8, 1)
                 }
             }
             sq_pid = kInvalid;
         }
+        QP_MARK(11)
 
         if (took) {
             // (nothing: ids and distances came from the helpers)
@@ -1687,15 +1731,43 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             if (dlog.log && fresh) tab_idx = vis_index(vis, nb_pid);
         }
 
+        QP_MARK(3)
         // four-wave walk: hand the row of the candidate expected next to the helpers — they work on it while this wave pushes
         if constexpr (kSpec) {
-            bool ask = !sq_off && pf_pid != kInvalid;
+            // The candidate the next pop returns is known before the merge: the smaller of the first old un-expanded entry
+            // (peeked above) and the smallest new key, if that one gets in.  A new one: its adjacency row is requested now
+            // (in flight during the push) and nobody guesses; an old one: its row came with the requests above.
+            bool next_is_new = false;
+            if (na) {
+                uint64_t mn = fresh ? (((uint64_t)my_d << 32) | my_id) : ~0ull;
+                for (int sh = 32; sh >= 1; sh >>= 1) {
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mn, sh, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mn >> 32), sh, 64);
+                    const uint64_t o = ((uint64_t)hi << 32) | lo;
+                    mn = o < mn ? o : mn;
+                }
+                const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
+                next_is_new = mn < pk_key && mn < thr;
+                if (next_is_new) {
+                    pf2_pid = pf_pid; pf2_row = pf_row;
+                    pf_pid = (uint32_t)mn;
+                    pf_row = row_lane ? rows[(size_t)pf_pid * row_stride + lane] : kInvalid;
+                }
+            }
+            bool ask = !sq_off && !next_is_new && pf_pid != kInvalid;
             if constexpr (!walk_vis16(LAT)) ask = ask && vis.tab != nullptr && !vis.spill && vis.count + 128u <= vis.tlimit;
+            const bool pending = took && !walk_vis16(LAT);            // the taken ids still have to enter the id set
             if (ask) {
-                quad_post_spec(*quad, pf_row);
+                quad_post_spec(*quad, pf_row, act_dist, pending && fresh ? my_id : kInvalid, pending ? (uint32_t)na : 0u);
                 sq_pid = pf_pid;
+                QP_CNT(9, 1)
+            }
+            if (pending) {
+                visited_begin(vis);
+                if (fresh) tab_idx = tab_insert(vis, my_id);
+                visited_added(vis, (uint32_t)na);
             }
         }
+        QP_MARK(4)
 
         if (na) {                                                                       // Search::push in slot order, :606-608
             ctr.n_dist += (uint32_t)na;
@@ -1704,8 +1776,10 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             w_push_keys<push_chunks<LAT>()>(st, key, fresh);
         }
         w_truncate(st);                                    // :612
+        QP_MARK(5) QP_CNT(10, na)
         if (++guard > ix.n + 64u) { st.status |= kStGuard; break; }
     }
+    QP_FLUSH(kSpec && is_zero)
 }
 
 // n_dist / n_rows: work as executed here.  n_ref: distance calls as the REFERENCE makes them — `any` stops at the first
