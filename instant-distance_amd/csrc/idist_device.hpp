@@ -1349,12 +1349,19 @@ __device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const floa
                     other = st == kQFull;
                 } else {
                     fresh = !tab_find(vis, id);
-                    const uint32_t cn = uniform_u32(ctl->commit_n);             // (see quad_post_spec)
+                }
+            }
+            if constexpr (!walk_vis16(LAT)) {
+                // ids on their way into the set count as visited (quad_post_spec); all reads of the list in flight together
+                if (uniform_u32(ctl->commit_n)) {
                     const uint4* c4 = reinterpret_cast<const uint4*>(act_dist);
-                    for (uint32_t j = 0; 4u * j < cn; j++) {
-                        const uint4 c = c4[j];
-                        if (id == c.x || id == c.y || id == c.z || id == c.w) fresh = false;
-                    }
+                    uint4 c[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) c[j] = c4[j];
+                    bool hit = false;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) hit = hit || id == c[j].x || id == c[j].y || id == c[j].z || id == c[j].w;
+                    fresh = fresh && !hit;
                 }
             }
             if (__ballot(other)) {
@@ -1739,14 +1746,18 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             // (in flight during the push) and nobody guesses; an old one: its row came with the requests above.
             bool next_is_new = false;
             if (na) {
-                uint64_t mn = fresh ? (((uint64_t)my_d << 32) | my_id) : ~0ull;
-                for (int sh = 32; sh >= 1; sh >>= 1) {
-                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mn, sh, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(mn >> 32), sh, 64);
-                    const uint64_t o = ((uint64_t)hi << 32) | lo;
-                    mn = o < mn ? o : mn;
-                }
                 const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
-                next_is_new = mn < pk_key && mn < thr;
+                const uint64_t bar = pk_key < thr ? pk_key : thr;
+                const uint64_t mine = ((uint64_t)my_d << 32) | my_id;
+                uint64_t bm = __ballot(fresh && mine < bar);                   // usually none or a few: scalar minimum over them
+                next_is_new = bm != 0ull;
+                uint64_t mn = ~0ull;
+                while (bm) {
+                    const int i = __builtin_ctzll(bm);
+                    bm &= bm - 1ull;
+                    const uint64_t k = ((uint64_t)readlane_u32(my_d, i) << 32) | readlane_u32(my_id, i);
+                    mn = k < mn ? k : mn;
+                }
                 if (next_is_new) {
                     pf2_pid = pf_pid; pf2_row = pf_row;
                     pf_pid = (uint32_t)mn;
