@@ -1238,24 +1238,19 @@ struct Counters {
 // kQuadExit releases the helpers when the leader's work queue is empty.  Decisions, their order and the
 // arithmetic per row are those of the other variants: results are bit-identical.
 // ---------------------------------------------------------------------------
-// Round 4 — the helpers work AHEAD, and the leader computes no distances at all on the zero layer.  The leader's share of an
-// expansion that is not a distance pass (pop, visited set, push: ~1.9 us of ~4.1) used to leave three SIMDs idle, and the pass
-// left the leader's bookkeeping waiting.  Now:
-//   * the candidate the next pop returns is known BEFORE the merge of an expansion's keys — the smaller of the first old
-//     un-expanded entry behind the current one and the smallest new key that gets in — so the leader hands that candidate's
-//     adjacency row to the helpers (the old one's was requested one or two expansions earlier; a new one's is requested at
-//     once and handed over after the push) and goes on inserting and pushing;
-//   * the helpers compute the distance of EVERY id of that row, in slot order, three ways split — they never look at the
-//     visited set, so nothing the leader does meanwhile can change what they produce, and rows of ids that turn out to be
-//     known are the price (~15 % more rows at ef 100, ~27 % at ef 400 — of a walk that uses a fraction of a per cent of the
-//     bandwidth);
-//   * at the next pop the leader looks the row up itself (known / new, the bitmap's answers included), keeps the distances of
-//     the new ids — the bits its own pass would have produced, the arithmetic per row is the same — and pushes them in slot
-//     order.  A candidate nobody was asked about (the entry point, a refill of spilled ties) takes the shared pass as before.
+// Round 4 — the helpers also work AHEAD.  The leader's share of an expansion that is not a distance pass (pop, visited set,
+// push: ~1.9 us of ~4.1) used to leave three SIMDs idle.  Now the leader names the candidate it expects to pop next (the first
+// un-expanded entry behind the current one; a replay of the walk says it is the one 89 % of the time at ef 100, 97 % at ef 400)
+// and hands its adjacency row over; while the leader pushes, the helpers look that row's ids up in the visited set (read only),
+// compact the new ones in slot order and compute their distances.  If the next pop is that candidate, the leader takes ids and
+// distances as they are — nothing changed the visited set in between (ids enter it inside distance passes only), so they are
+// exactly what its own look-up and pass would produce — inserts the ids, pushes in slot order, and no distance pass stands
+// between two pushes.  Otherwise the results are ignored.  Speculation is only asked for while the on-chip set answers every
+// look-up alone (no id in the bitmap: narrow batches at ef_search ~100 never get there).
 // Commands, each behind one workgroup barrier A (helpers loop: A, read command, act):
 //     kQuadPass(na)  all four waves take their share of act_pid[0..na), then barrier B
-//     kQuadSpec      helpers: distances of ctl->spec_row, all slots
-//     kQuadTake      nothing — the barrier itself is the hand-over: helpers arrive at A when they are done
+//     kQuadSpec      helpers: speculate on ctl->spec_row (the row of ctl->spec_pid)
+//     kQuadTake      nothing — the barrier itself is the hand-over: helpers arrive at A when their speculation is done
 //     kQuadExit      helpers leave
 // Measurement build (make probe): where the leader of a four-wave walk and its helpers spend a zero-layer walk — 10-ns ticks
 // per segment, summed over all walks since the last reset (idist_probe_quad in idist_capi.hip).
@@ -1272,14 +1267,15 @@ __device__ unsigned long long g_quad_probe[24];
 #define QP_FLUSH(on)
 #endif
 enum : uint32_t { kQuadPass = 0, kQuadSpec = 1, kQuadTake = 2, kQuadExit = 3 };
+constexpr uint32_t kSpecAbort = 0xFFFFFFFFu;            // spec_n: the row holds an id only the bitmap can answer for
 // The command word and the row count are kept TWICE, by the parity of the barrier they belong to: after barrier k the helpers
 // read cmd[k & 1] while the leader may already be writing cmd[(k + 1) & 1] for its next command (nothing but that barrier
 // stands between "the helpers were released" and "the leader posts again").  Every wave counts the A barriers it passed.
 struct QuadCtl {
-    uint32_t cmd[2], na[2], pad[4];
-    uint32_t spec_row[64];                               // leader -> helpers: the next candidate's adjacency row (slot order)
-    uint32_t spec_ids[64];                               // helpers: the row with out-of-range ids replaced (never read by the leader)
-    uint32_t spec_dist[64];                              // helpers -> leader: canonical distance bits, by slot
+    uint32_t cmd[2], na[2], spec_n, pad[3];
+    uint32_t spec_row[64];                               // leader -> helpers: the predicted candidate's adjacency row (slot order)
+    uint32_t spec_new[64];                               // helpers -> leader: its new ids, compacted in slot order
+    uint32_t spec_dist[64];                              // ... and their canonical distance bits
 };
 // the leader's end of the protocol: the control block and the number of A barriers passed so far (wave-uniform, in registers)
 struct QuadLead {
@@ -1302,13 +1298,16 @@ __device__ __forceinline__ void quad_dist_pass(const IndexView& ix, const float*
     dist_rounds_quad<NB, RS, TAIL>(ix, q, act_pid, act_dist, na, 0, mid);
     block_sync();                                                      // B
 }
-// leader: hand the next candidate's row to the helpers (row_id: this lane's slot of it, kInvalid beyond its end)
+// leader: hand the predicted candidate's row to the helpers (row_id: this lane's slot of it, kInvalid beyond its end)
 __device__ __forceinline__ void quad_post_spec(QuadLead& ql, uint32_t row_id) {
     ql.ctl->spec_row[lane_id()] = row_id;
     ql.post(kQuadSpec);
 }
-// leader: wait for the distances it asked for (ctl->spec_dist, by slot)
-__device__ __forceinline__ void quad_take_spec(QuadLead& ql) { ql.post(kQuadTake); }   // the helpers arrive at A when they are done
+// leader: wait for the speculation it asked for; number of new ids in ctl->spec_new / spec_dist, or kSpecAbort
+__device__ __forceinline__ uint32_t quad_take_spec(QuadLead& ql) {
+    ql.post(kQuadTake);                                                // the helpers arrive at A when they are done
+    return uniform_u32(ql.ctl->spec_n);
+}
 // the helpers' three-way split of a speculated list: wave wv (1..3) takes rounds wv - 1, wv + 2, ... of 8 rows
 template <int NB, int RS, int TAIL>
 __device__ __forceinline__ void dist_rounds_spec(const IndexView& ix, const float* q, const uint32_t* pids, uint32_t* dists, int na, int wv) {
@@ -1321,7 +1320,7 @@ __device__ __forceinline__ void dist_rounds_spec(const IndexView& ix, const floa
 }
 template <int NB, int RS, int TAIL, int LAT>
 __device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const float* q, QuadCtl* ctl, const uint32_t* act_pid,
-                                                 uint32_t* act_dist, int wv) {
+                                                 uint32_t* act_dist, int wv, const Visited& vis) {
     const int lane = lane_id();
     for (uint32_t seq = 0;; seq++) {
         block_sync();                                                  // A number `seq`
@@ -1334,16 +1333,31 @@ __device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const floa
 #ifdef IDIST_PROBE
             const unsigned long long hp0 = wall_clock64();
 #endif
-            uint32_t id = ctl->spec_row[lane];
+            const uint32_t id = ctl->spec_row[lane];
             const uint64_t inval = __ballot(id == kInvalid);
             const int nv = inval ? __builtin_ctzll(inval) : 64;
-            if (id >= ix.n) id = 0u;                                   // (a broken row: the leader reports it, kStBadRow)
-            ctl->spec_ids[lane] = id;                                  // (the same values from all three helpers)
+            bool fresh = false, other = false;                         // other: only the bitmap knows
+            if (lane < nv && id < ix.n) {
+                if constexpr (walk_vis16(LAT)) {
+                    const int st = q16_lookup(vis, id);
+                    fresh = st == kQRoom;
+                    other = st == kQFull;
+                } else {
+                    fresh = !tab_find(vis, id);
+                }
+            }
+            if (__ballot(other)) {
+                if (wv == 1 && lane == 0) ctl->spec_n = kSpecAbort;
+                continue;
+            }
+            const uint64_t fm = __ballot(fresh);
+            if (fresh) ctl->spec_new[__popcll(fm & ((1ull << lane) - 1ull))] = id;   // (the same values from all three helpers)
+            if (wv == 1 && lane == 0) ctl->spec_n = (uint32_t)__popcll(fm);
             wave_sync();
 #ifdef IDIST_PROBE
             const unsigned long long hp1 = wall_clock64();
 #endif
-            dist_rounds_spec<NB, RS, TAIL>(ix, q, ctl->spec_ids, ctl->spec_dist, nv, wv);
+            dist_rounds_spec<NB, RS, TAIL>(ix, q, ctl->spec_new, ctl->spec_dist, __popcll(fm), wv);
 #ifdef IDIST_PROBE
             if (lane == 0) {
                 const unsigned long long hp2 = wall_clock64();
@@ -1499,6 +1513,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     [[maybe_unused]] uint32_t pf2_pid = kInvalid, pf2_row = kInvalid;   // adjacency requested two expansions ahead
     [[maybe_unused]] uint64_t pk_key = ~0ull;             // key of the first old un-expanded entry behind the current candidate
     [[maybe_unused]] uint32_t sq_pid = kInvalid;          // the candidate whose row the helpers were given (wave-uniform)
+    [[maybe_unused]] bool sq_off = false;                 // this layer met an id only the bitmap answers for: no more guesses
     QP_DECL
     for (;;) {
         int ci = w_pop(st);                               // :599-604
@@ -1561,22 +1576,43 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         if (is_nb && nb_pid >= ix.n) st.status |= kStBadRow;
         const bool ok_nb = is_nb && nb_pid < ix.n;
 
-        // four-wave walk: the helpers were given this candidate's row — the distance of every slot is theirs (QuadCtl); what is
-        // left for the branches below is the visited set, and the inserts wait until the next row is handed over (ins_*)
+        // four-wave walk: did the helpers work this expansion out in advance (QuadCtl)?
         [[maybe_unused]] bool took = false;
-        [[maybe_unused]] bool ins_sure = false, ins_tab = false;
         QP_MARK(1)
         if constexpr (kSpec) {
             if (sq_pid != kInvalid && sq_pid == cpid) {
-                quad_take_spec(*quad);
-                took = true;
-                QP_CNT(7, 1)
+                const uint32_t ns = quad_take_spec(*quad);
+                QP_MARK(2)
+                if (ns != kSpecAbort) {
+                    QP_CNT(7, 1)
+                    took = true;
+                    na = (int)ns;
+                    fresh = lane < na;
+                    my_id = fresh ? quad->ctl->spec_new[lane] : kInvalid;
+                    my_d = fresh ? quad->ctl->spec_dist[lane] : 0u;
+                    // the inserts a distance pass would have made while its rows were in flight
+                    if constexpr (walk_vis16(LAT)) {
+                        if (fresh && q16_insert(vis, my_id, tab_idx) == kQFull) {       // filled up by this very expansion
+                            atomicOr(&vis.bits[my_id >> 5], 1u << (my_id & 31u));
+                            visited_note(vis, my_id);
+                        }
+                    } else {
+                        visited_begin(vis);
+                        if (fresh) tab_idx = tab_insert(vis, my_id);
+                        visited_added(vis, (uint32_t)na);
+                    }
+                } else {
+                    sq_off = true;                                    // an id of the bitmap class: no more guesses on this layer
+                    QP_CNT(8, 1)
+                }
             }
             sq_pid = kInvalid;
         }
-        QP_MARK(2)
+        QP_MARK(11)
 
-        if constexpr (walk_vis16(LAT)) {
+        if (took) {
+            // (nothing: ids and distances came from the helpers)
+        } else if constexpr (walk_vis16(LAT)) {
             // visited.insert(pid), core/lib.rs:705 / core/types.rs:32-40, on the quotient set: one LDS round trip tells
             // every neighbour apart — known / surely new (a home bucket has room: it never went to the bitmap) / both
             // home buckets full (the bitmap decides).  The surely new ones go to the distance pass at once and enter the
@@ -1591,12 +1627,10 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 if (stt == kQFull) vold = atomicOr(&vis.bits[nb_pid >> 5], vbit);
             }
             const bool sure = ok_nb && stt == kQRoom, maybe = ok_nb && stt == kQFull;
+            if constexpr (kSpec) { if (__ballot(maybe)) sq_off = true; }
             const uint64_t sm = __ballot(sure);
             wave_sync();
-            if (took) {
-                ins_sure = sure;
-                my_d = quad->ctl->spec_dist[lane];
-            } else if (sm) {
+            if (sm) {
                 const int my = __popcll(sm & ((1ull << lane) - 1ull));
                 if (sure) act_pid[my] = nb_pid;                                         // keeps slot order
                 wave_sync();
@@ -1615,7 +1649,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             if (late) visited_note(vis, nb_pid);
             const uint64_t lm = __ballot(late);
             wave_sync();
-            if (lm && !took) {
+            if (lm) {
                 const int my = __popcll(lm & ((1ull << lane) - 1ull));
                 if (late) act_pid[my] = nb_pid;
                 wave_sync();
@@ -1641,10 +1675,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             na = __popcll(fm);
             visited_added(vis, (uint32_t)na);
             wave_sync();
-            if (took) {
-                ins_tab = defer && fresh;
-                my_d = quad->ctl->spec_dist[lane];
-            } else if (na) {
+            if (na) {
                 const int my = __popcll(fm & ((1ull << lane) - 1ull));
                 if (fresh) act_pid[my] = nb_pid;                                        // keeps slot order
                 wave_sync();
@@ -1694,11 +1725,12 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         }
 
         QP_MARK(3)
-        // four-wave walk: the candidate the next pop returns is known before the merge — the smaller of the first old un-expanded
-        // entry (peeked above) and the smallest new key, if that one gets in.  An old one: its row came with the requests above and
-        // goes to the helpers now; a new one: its adjacency row is requested now and handed over after the push.
-        [[maybe_unused]] bool next_is_new = false;
+        // four-wave walk: hand the row of the candidate expected next to the helpers — they work on it while this wave pushes
+        [[maybe_unused]] bool next_is_new = false, ask = false;
         if constexpr (kSpec) {
+            // The candidate the next pop returns is known before the merge: the smaller of the first old un-expanded entry
+            // (peeked above) and the smallest new key, if that one gets in.  An old one: its row came with the requests above and
+            // goes to the helpers now; a new one: its adjacency row is requested now and handed over after the push.
             if (na) {
                 const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
                 const uint64_t bar = pk_key < thr ? pk_key : thr;
@@ -1718,19 +1750,12 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                     pf_row = row_lane ? rows[(size_t)pf_pid * row_stride + lane] : kInvalid;
                 }
             }
-            if (!next_is_new && pf_pid != kInvalid) {
+            ask = !sq_off && pf_pid != kInvalid;
+            if constexpr (!walk_vis16(LAT)) ask = ask && vis.tab != nullptr && !vis.spill && vis.count + 128u <= vis.tlimit;
+            if (ask && !next_is_new) {
                 quad_post_spec(*quad, pf_row);
                 sq_pid = pf_pid;
                 QP_CNT(9, 1)
-            }
-            // the inserts a distance pass would have made while its rows were in flight
-            if constexpr (walk_vis16(LAT)) {
-                if (ins_sure && q16_insert(vis, nb_pid, tab_idx) == kQFull) {           // filled up by this very expansion
-                    atomicOr(&vis.bits[nb_pid >> 5], 1u << (nb_pid & 31u));
-                    visited_note(vis, nb_pid);
-                }
-            } else {
-                if (ins_tab) tab_idx = tab_insert(vis, nb_pid);
             }
         }
         QP_MARK(4)
@@ -1743,10 +1768,10 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         }
         w_truncate(st);                                    // :612
         if constexpr (kSpec) {
-            if (next_is_new && pf_pid != kInvalid) {       // (its row has had the push to arrive)
+            if (ask && next_is_new) {                      // a new candidate: its row has had the push to arrive
                 quad_post_spec(*quad, pf_row);
                 sq_pid = pf_pid;
-                QP_CNT(8, 1)
+                QP_CNT(9, 1)
             }
         }
         QP_MARK(5) QP_CNT(10, na)

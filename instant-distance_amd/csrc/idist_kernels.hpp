@@ -195,7 +195,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
     if constexpr (walk_quad(LAT)) {
         const int wv = (int)uniform_u32(threadIdx.x >> 6);
         if (wv != 0) {                                                 // (the helpers only ever READ the on-chip set through `vis`)
-            quad_helper_loop<NB, RS, TAIL, LAT>(ix, sm.q, sm.ctl, sm.act_pid, sm.act_dist, wv);
+            quad_helper_loop<NB, RS, TAIL, LAT>(ix, sm.q, sm.ctl, sm.act_pid, sm.act_dist, wv, vis);
             return;
         }
     }
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
     if constexpr (walk_quad(LAT)) {
         const int wv = (int)uniform_u32(threadIdx.x >> 6);
         if (wv != 0) {                                                 // (the helpers only ever READ the on-chip set through `vis`)
-            quad_helper_loop<NB, RS, TAIL, LAT>(ix, sm.q, sm.ctl, sm.act_pid, sm.act_dist, wv);
+            quad_helper_loop<NB, RS, TAIL, LAT>(ix, sm.q, sm.ctl, sm.act_pid, sm.act_dist, wv, vis);
             return;
         }
     }

@@ -55,11 +55,11 @@ for ef in (100, 400):
     rec = {"probe": "quad_walk_segments", "commit": bench.source_stamp(), "dim": dim, "ef_search": ef, "calls": calls,
            "kernel_ms_median": round(float(np.median(times)), 4),
            "expansions_per_call": round(nexp / calls, 1), "new_ids_per_expansion": round(p[10] / nexp, 1),
-           "handed_over_before_the_push": round(p[9] / nexp, 3), "handed_over_after_the_push": round(p[8] / nexp, 3), "taken": round(p[7] / nexp, 3),
+           "asked": round(p[9] / nexp, 3), "taken": round(p[7] / nexp, 3), "aborted": round(p[8] / nexp, 4),
            "leader_ns_per_expansion": {"pop": ns(p[0]), "adjacency_and_peeks": ns(p[1]), "wait_for_helpers": ns(p[2]),
-                                       "visited_lookup_or_own_pass": ns(p[3]), "next_candidate_hand_over_inserts": ns(p[4]),
-                                       "push_truncate_late_hand_over": ns(p[5]), "sum": ns(p[0] + p[1] + p[2] + p[3] + p[4] + p[5])},
-           "helper_ns_per_request": {f"wave{w + 1}": {"row_ids": round(p[12 + 3 * w] * 10 / max(p[14 + 3 * w], 1), 1),
+                                       "inserts_after_take": ns(p[11]), "own_pass_when_not_taken": ns(p[3]), "post_request": ns(p[4]),
+                                       "push_and_truncate": ns(p[5]), "sum": ns(p[0] + p[1] + p[2] + p[11] + p[3] + p[4] + p[5])},
+           "helper_ns_per_request": {f"wave{w + 1}": {"lookup": round(p[12 + 3 * w] * 10 / max(p[14 + 3 * w], 1), 1),
                                                      "rows": round(p[13 + 3 * w] * 10 / max(p[14 + 3 * w], 1), 1),
                                                      "requests": int(p[14 + 3 * w])} for w in range(3)}}
     print(json.dumps(rec), file=out, flush=True)
