@@ -1240,13 +1240,23 @@ struct Counters {
 // ---------------------------------------------------------------------------
 // Round 4 — the helpers also work AHEAD.  The leader's share of an expansion that is not a distance pass (pop, visited set,
 // push: ~1.9 us of ~4.1) used to leave three SIMDs idle.  Now the leader names the candidate it expects to pop next (the first
-// un-expanded entry behind the current one; a replay of the walk says it is the one 89 % of the time at ef 100, 97 % at ef 400)
-// and hands its adjacency row over; while the leader pushes, the helpers look that row's ids up in the visited set (read only),
-// compact the new ones in slot order and compute their distances.  If the next pop is that candidate, the leader takes ids and
-// distances as they are — nothing changed the visited set in between (ids enter it inside distance passes only), so they are
-// exactly what its own look-up and pass would produce — inserts the ids, pushes in slot order, and no distance pass stands
-// between two pushes.  Otherwise the results are ignored.  Speculation is only asked for while the on-chip set answers every
-// look-up alone (no id in the bitmap: narrow batches at ef_search ~100 never get there).
+// un-expanded entry behind the current one) and hands its adjacency row over; while the leader pushes, the helpers look that
+// row's ids up in the visited set (read only), compact the new ones in slot order and compute their distances.  If the next
+// pop is that candidate, the leader takes ids and distances as they are — nothing changed the visited set in between (ids
+// enter it inside distance passes only), so they are exactly what its own look-up and pass would produce — inserts the ids,
+// pushes in slot order, and no distance pass stands between two pushes.  Otherwise the results are ignored.  Speculation is
+// only asked for while the on-chip set answers every look-up alone (no id in the bitmap: narrow batches at ef_search ~100
+// never get there).
+// Measured (make probe + scripts/probe_r04_quad.py, C3 index, one query per call, ef 100): the guess is asked for on 98 % of the
+// expansions and is right on 67 % of them (the others pop a key the expansion itself just pushed); per expansion the leader
+// spends ~0.3 us popping, ~1.0 on the adjacency row and the peek (a cold row on the 33 %), ~0.45 waiting for the helpers,
+// ~0.55 inserting, ~0.85 in its own passes, ~1.0 pushing; the helpers need ~0.4 us for the look-up and 1.6-1.9 for the rows.
+// The leader's serial chain bounds the walk, so what the protocol buys is small: 0.478 ms against 0.487 without it, same box
+// (profiles/probe_r04_quad_variants_same_box.jsonl).  Three richer protocols were built and measured on that box and dropped:
+// knowing the next candidate before the merge (smallest new key against the first old un-expanded entry: every guess right,
+// new candidates' rows requested during the push) costs the leader more per expansion than the saved waits return (0.497);
+// adjacency two expansions ahead (0.485); helpers computing every slot of the row without looking at the set (0.494 in its
+// own session, and the 100k x 128 build loses 3 % to the extra rows).
 // Commands, each behind one workgroup barrier A (helpers loop: A, read command, act):
 //     kQuadPass(na)  all four waves take their share of act_pid[0..na), then barrier B
 //     kQuadSpec      helpers: speculate on ctl->spec_row (the row of ctl->spec_pid)
@@ -1510,8 +1520,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     uint32_t pf_pid = kInvalid, pf_row = kInvalid;
     // four-wave walk with the visited set on chip: the helpers work one expansion ahead (QuadCtl)
     constexpr bool kSpec = walk_quad(LAT) && walk_vis_lds(LAT) && PFA;
-    [[maybe_unused]] uint32_t pf2_pid = kInvalid, pf2_row = kInvalid;   // adjacency requested two expansions ahead
-    [[maybe_unused]] uint64_t pk_key = ~0ull;             // key of the first old un-expanded entry behind the current candidate
     [[maybe_unused]] uint32_t sq_pid = kInvalid;          // the candidate whose row the helpers were given (wave-uniform)
     [[maybe_unused]] bool sq_off = false;                 // this layer met an id only the bitmap answers for: no more guesses
     QP_DECL
@@ -1528,32 +1536,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
 
         // layer.nearest_iter(pid).take(links): stop at first INVALID (core/types.rs:183-187)
         uint32_t nb_pid = kInvalid;
-        if constexpr (kSpec) {
-            // The helpers need the NEXT candidate's row while this expansion still runs, i.e. an expansion earlier than the
-            // walk itself does: adjacency rows are requested TWO expansions ahead (pf2: the candidate expected after the next
-            // one), so that the row handed to the helpers has had a whole expansion to arrive.
-            if (cpid == pf_pid) nb_pid = pf_row;
-            else if (cpid == pf2_pid) nb_pid = pf2_row;
-            else if (row_lane) nb_pid = rows[(size_t)cpid * row_stride + lane];
-            const int c2 = w_peek_next(st, ci);
-            pk_key = c2 >= 0 ? (st.W[c2] & kKeyMask) : ~0ull;
-            const uint32_t n_pid = c2 >= 0 ? (uint32_t)st.W[c2] : kInvalid;
-            uint32_t n_row = kInvalid;
-            if (n_pid != kInvalid) {
-                if (n_pid == pf2_pid) n_row = pf2_row;                                   // (the usual case: asked for last time)
-                else if (n_pid == pf_pid) n_row = pf_row;
-                else if (row_lane) n_row = rows[(size_t)n_pid * row_stride + lane];
-            }
-            const int c3 = c2 >= 0 ? w_peek_next(st, c2) : -1;
-            const uint32_t m_pid = c3 >= 0 ? (uint32_t)st.W[c3] : kInvalid;
-            uint32_t m_row = kInvalid;
-            if (m_pid != kInvalid) {
-                if (m_pid == pf2_pid) m_row = pf2_row;
-                else if (row_lane) m_row = rows[(size_t)m_pid * row_stride + lane];
-            }
-            pf_pid = n_pid; pf_row = n_row;
-            pf2_pid = m_pid; pf2_row = m_row;
-        } else if constexpr (PFA) {
+        if constexpr (PFA) {
             if (cpid == pf_pid) nb_pid = pf_row;
             else if (row_lane) nb_pid = rows[(size_t)cpid * row_stride + lane];
             const int c2 = w_peek_next(st, ci);
@@ -1726,33 +1709,10 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
 
         QP_MARK(3)
         // four-wave walk: hand the row of the candidate expected next to the helpers — they work on it while this wave pushes
-        [[maybe_unused]] bool next_is_new = false, ask = false;
         if constexpr (kSpec) {
-            // The candidate the next pop returns is known before the merge: the smaller of the first old un-expanded entry
-            // (peeked above) and the smallest new key, if that one gets in.  An old one: its row came with the requests above and
-            // goes to the helpers now; a new one: its adjacency row is requested now and handed over after the push.
-            if (na) {
-                const uint64_t thr = st.plen >= st.ef ? (st.ef ? (st.W[st.ef - 1] & kKeyMask) : 0ull) : kMaxKey + 1ull;
-                const uint64_t bar = pk_key < thr ? pk_key : thr;
-                const uint64_t mine = ((uint64_t)my_d << 32) | my_id;
-                uint64_t bm = __ballot(fresh && mine < bar);                   // usually none or a few: scalar minimum over them
-                next_is_new = bm != 0ull;
-                uint64_t mn = ~0ull;
-                while (bm) {
-                    const int i = __builtin_ctzll(bm);
-                    bm &= bm - 1ull;
-                    const uint64_t k = ((uint64_t)readlane_u32(my_d, i) << 32) | readlane_u32(my_id, i);
-                    mn = k < mn ? k : mn;
-                }
-                if (next_is_new) {
-                    pf2_pid = pf_pid; pf2_row = pf_row;
-                    pf_pid = (uint32_t)mn;
-                    pf_row = row_lane ? rows[(size_t)pf_pid * row_stride + lane] : kInvalid;
-                }
-            }
-            ask = !sq_off && pf_pid != kInvalid;
+            bool ask = !sq_off && pf_pid != kInvalid;
             if constexpr (!walk_vis16(LAT)) ask = ask && vis.tab != nullptr && !vis.spill && vis.count + 128u <= vis.tlimit;
-            if (ask && !next_is_new) {
+            if (ask) {
                 quad_post_spec(*quad, pf_row);
                 sq_pid = pf_pid;
                 QP_CNT(9, 1)
@@ -1767,13 +1727,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             w_push_keys<push_chunks<LAT>()>(st, key, fresh);
         }
         w_truncate(st);                                    // :612
-        if constexpr (kSpec) {
-            if (ask && next_is_new) {                      // a new candidate: its row has had the push to arrive
-                quad_post_spec(*quad, pf_row);
-                sq_pid = pf_pid;
-                QP_CNT(9, 1)
-            }
-        }
         QP_MARK(5) QP_CNT(10, na)
         if (++guard > ix.n + 64u) { st.status |= kStGuard; break; }
     }
