@@ -9,6 +9,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite is dominated by the lockstep emulator and every test is independent: with pytest-xdist installed and
+    no explicit -n, a `-m "not gpu"` run is spread over the host cores (a quarter of an hour becomes two minutes).  Runs that
+    touch the GPU (`-m gpu`, or no marker expression at all) stay in one process; IDIST_TEST_WORKERS=0 switches this off."""
+    opt = config.option
+    if os.environ.get("PYTEST_XDIST_WORKER") or os.environ.get("IDIST_TEST_WORKERS", "") == "0":
+        return None
+    if getattr(opt, "numprocesses", 0) is None and (opt.markexpr or "").strip() == "not gpu" and not getattr(opt, "usepdb", False):
+        try:
+            import xdist  # noqa: F401
+        except ImportError:
+            return None
+        n = int(os.environ.get("IDIST_TEST_WORKERS", 0)) or min(6, os.cpu_count() or 1)
+        if n > 1:
+            opt.numprocesses = n
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

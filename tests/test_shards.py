@@ -89,8 +89,8 @@ def test_context_is_bound_to_its_index_not_to_an_address(eng, oracle):
     addr_a = a._h.value
     del a                                                             # frees index A; ctx outlives it
     seen_same_address = False
-    for _ in range(8):
-        b = ida.Hnsw.from_ordered_points(rng.random((S(kind, 400, 4000), 6), dtype=np.float32), ida.Builder())
+    for _ in range(S(kind, 4, 8)):
+        b = ida.Hnsw.from_ordered_points(rng.random((S(kind, 150, 4000), 6), dtype=np.float32), ida.Builder())
         seen_same_address |= b._h.value == addr_a
         q = np.zeros((1, 6), dtype=np.float32)
         pid = np.zeros((1, 100), dtype=np.uint32)
