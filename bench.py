@@ -256,7 +256,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-build-sample", type=int, default=-1, help="points of the prefix the CPU oracle builds (threaded); 0 = skip")
     ap.add_argument("--check", action="store_true", help="add the `checks` object (size-independent properties; used by tests/)")
-    ap.add_argument("--threads", default="1,4,16", help="host-thread counts of the scalar-call measurement ('' = skip)")
+    ap.add_argument("--threads", default="1,4,16,64", help="host-thread counts of the scalar-call measurement ('' = skip)")
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that fill roofline.traffic (N = 1 only)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child of measure_traffic()
