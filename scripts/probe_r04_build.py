@@ -34,6 +34,9 @@ CASES = {
     "check": {"IDIST_BUILD_CHECK": "1"},                                        # both zero-layer copies must agree at the end
     "no_dlog": {"IDIST_BUILD_NO_DLOG": "1"},
     "no_quad": {"IDIST_BUILD_QUAD": "0"},
+    "growth16": {"IDIST_BUILD_GROWTH": "16"},                                   # narrow steps hold g / 16 insertions instead of g / 32
+    "growth8": {"IDIST_BUILD_GROWTH": "8"},
+    "growth16_check": {"IDIST_BUILD_GROWTH": "16", "IDIST_BUILD_CHECK": "1"},
     "regs512": {"IDIST_BUILD_A_REGS": "512"},                                   # descents: one 512-register wave per SIMD, four per CU
     "regs512_w3": {"IDIST_BUILD_A_REGS": "512", "IDIST_BUILD_A_WAVES": "3"},
     # (the session of commit d4e16c2 — profiles/probe_r04b_build_schedule.jsonl — had the layout under two knobs:
