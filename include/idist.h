@@ -49,6 +49,8 @@
  *   IDIST_BUILD_CHECK=1     self-check at the end of a pipelined build: both copies of the zero layer must agree
  *   IDIST_BUILD_A_WAVES=<1..8>  descent waves per CU in the pipelined schedule (default 4; 3 with the id set)
  *   IDIST_BUILD_STREAMS=off|narrow|all  extra streams of the pipelined build: never / in narrow steps (default) / in every step
+ *   IDIST_BUILD_GROWTH=<8..32>  narrow steps of a concurrent build hold g / d insertions, g = points already in (default 8;
+ *                           wide steps always g / 32); graphs differ, quality does not
  *   IDIST_BUILD_A2=tile     new points' select_heuristic with the LDS-tile kernel instead of the Gram matrix on MFMA
  *   IDIST_BUILD_NO_FAST=1   every neighbour update through the from-scratch kernel (no memoised re-selection)
  *   IDIST_BUILD_NO_DLOG=1   the memoised re-selection recomputes every distance instead of looking it up
