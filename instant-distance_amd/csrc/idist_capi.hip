@@ -548,9 +548,6 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // ≈ 180 (100k x 128: 0.156 -> 0.122 s, 20k x 128: 0.078 -> 0.043 s, C3 -2.6 %; recall@10 unchanged to the fourth digit at
     // 5k / 20k / 100k / 1M points, profiles/probe_r04_build_growth_*.jsonl).  IDIST_BUILD_GROWTH=<d> (A/B knob, 8..32): g / d.
     uint32_t growth_div = 8u;
-    // IDIST_BUILD_SEQ=<8..64> (A/B knob; default 64): below this many points every insertion is a step of its own
-    uint32_t seq_below = 64u;
-    if (const char* e = getenv("IDIST_BUILD_SEQ")) seq_below = (uint32_t)std::min(64, std::max(8, atoi(e)));
     if (const char* e = getenv("IDIST_BUILD_GROWTH")) growth_div = (uint32_t)std::min(32, std::max(8, atoi(e)));
     // what one CU's LDS holds of them (the sequential schedule runs nothing beside the descents)
     const uint32_t a_waves_max = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)((160u * 1024u) / smem)));
@@ -709,7 +706,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             // top layer is sequential in the reference (:313-314); below, at most `cap` inserts run
             // concurrently (:316-318) and never more than 1/32 of the graph they search (1/8 while the step is narrow).
             uint32_t B = 1;
-            if (cap > 1 && (uint32_t)layer != top && g >= seq_below) B = std::min(cap, std::max(std::min(g / growth_div, quad_B), g / 32u));
+            if (cap > 1 && (uint32_t)layer != top && g >= 64) B = std::min(cap, std::max(std::min(g / growth_div, quad_B), g / 32u));
             B = std::min(B, end - g);
             a.start = g;
             a.count = B;

@@ -34,8 +34,6 @@ CASES = {
     "check": {"IDIST_BUILD_CHECK": "1"},                                        # both zero-layer copies must agree at the end
     "no_dlog": {"IDIST_BUILD_NO_DLOG": "1"},
     "no_quad": {"IDIST_BUILD_QUAD": "0"},
-    "seq16": {"IDIST_BUILD_SEQ": "16"},                                         # concurrent steps from 16 points on instead of 64
-    "seq8": {"IDIST_BUILD_SEQ": "8"},
     "growth16": {"IDIST_BUILD_GROWTH": "16"},                                   # narrow steps hold g / 16 insertions instead of g / 32
     "growth8": {"IDIST_BUILD_GROWTH": "8"},
     "growth16_check": {"IDIST_BUILD_GROWTH": "16", "IDIST_BUILD_CHECK": "1"},
