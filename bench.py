@@ -238,7 +238,7 @@ def scalar_calls(hnsw, ida, q_host, n_threads, calls):
     return n_threads * calls / dt
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -262,7 +262,516 @@ def main():
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child of measure_traffic()
     ap.add_argument("--no-inproc-rccl", action="store_true", help="N > 1: skip the in-process idist_replicate_rccl measurement after the run")
     ap.add_argument("--rccl-child", type=int, default=0, help=argparse.SUPPRESS)        # internal: devices of the in-process replication child
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+class Job:
+    """One rank's surroundings: the torch backend that carries the collectives, the device that holds the tensors, and (through
+    instant_distance_amd._capi) the libidist that answers.  main() makes the nccl (= RCCL) / cuda:LOCAL_RANK one.
+    tests/test_distributed_gloo.py makes gloo / cpu ones around the emulator build of the same sources, so every line of the
+    N > 1 control flow below (replication, ef agreement, barriers around the timed steps, max over ranks, replica digest, rank-0
+    oracle check) has run at world sizes 2 and 3 before an 8-GPU lease runs it.  `dist` is None for a plain `python bench.py`."""
+
+    def __init__(self, torch, rank=0, world=1, local_rank=0, dev=None, dist=None):
+        self.torch, self.rank, self.world, self.local_rank, self.dist = torch, rank, world, local_rank, dist
+        self.dev = dev if dev is not None else torch.device("cuda", local_rank)
+        self.cuda = self.dev.type == "cuda"
+        # tensors handed to collectives live where the backend wants them: in HBM for nccl, on the host for gloo
+        self.cdev = self.dev if (dist is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+
+    @property
+    def multi(self):
+        return self.dist is not None
+
+    def sync(self):
+        if self.cuda:
+            self.torch.cuda.synchronize()
+
+    def stream(self):
+        return self.torch.cuda.current_stream().cuda_stream if self.cuda else 0
+
+    def barrier(self):
+        if self.multi:
+            self.dist.barrier()
+
+    def reduce(self, value, dtype, op):
+        """all_reduce of one scalar; the identity without a process group"""
+        if not self.multi:
+            return value
+        t = self.torch.tensor([value], dtype=dtype, device=self.cdev)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return t.item()
+
+    def bcast_i64(self, value, src=0):
+        t = self.torch.tensor([value], dtype=self.torch.int64, device=self.cdev)
+        self.dist.broadcast(t, src=src)
+        return int(t.item())
+
+    def gather_i64(self, value):
+        ts = [self.torch.zeros(1, dtype=self.torch.int64, device=self.cdev) for _ in range(self.world)]
+        self.dist.all_gather(ts, self.torch.tensor([value], dtype=self.torch.int64, device=self.cdev))
+        return [int(t.item()) for t in ts]
+
+
+def phase_build(job, ida, builder, n, dim):
+    """Rank 0: synthetic points in HBM, Builder::build on the GPU.  -> (hnsw, d_pts, build object)"""
+    torch = job.torch
+    d_pts = synth(torch, n, dim, 123456789, job.dev)
+    job.sync()
+    t0 = time.time()
+    # (a host-transport job — gloo, tests — replicates from the host copy of the points; RCCL broadcasts the device buffers)
+    hnsw = ida.Hnsw.from_device_points(d_pts.data_ptr(), n, dim, builder, host_points=None if job.cuda else d_pts.numpy())
+    t_build = time.time() - t0
+    st = hnsw.build_stats()
+    secs = max(st.seconds, 1e-9)
+    build = {"points_per_s": round(n / secs, 1), "device_seconds": round(st.seconds, 3),
+             "wall_seconds": round(t_build, 3), "ef_construction": 100, "batches": int(st.n_batches),
+             "n_dist": int(st.n_dist), "n_sel_pairs": int(st.n_sel_pairs), "n_updates": int(st.n_updates),
+             "n_updates_memoised": int(st.n_updates_fast), "n_updates_full": int(st.n_updates_full),
+             "n_heur_rows": int(st.n_heur_rows),
+             "n_sel_pairs_note": "candidate pairs of select_heuristic decided here (by the Gram-matrix filter, a memoised "
+                                 "verdict or the canonical distance) — NOT the reference's early-exit count of distance calls"}
+    # Bytes the build's algorithm moves AS EXECUTED HERE: the descents (B_q with ef_construction on the partial
+    # graph), every point row fetched for select_heuristic / the neighbour re-selections (n_heur_rows; pairwise
+    # reuse is on chip, memoised verdicts fetch nothing), and the adjacency rows read + rewritten.
+    ab = int(st.n_dist * 4 * dim + st.n_exp0 * 256 + st.n_expU * 128 + st.n_heur_rows * 4 * dim
+             + st.n_updates * 512 + n * 256)
+    build["roofline"] = {"bound": "hbm", "achieved": round(ab / secs / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(ab / secs / 1e9 / HBM_PEAK_GBPS, 4), "alg_bytes": ab,
+                         "note": "all build kernels together over the build's device time; per-kernel PMC bytes: profiles/"}
+    return hnsw, d_pts, build
+
+
+def phase_replicate(job, idd, hnsw, builder):
+    """One broadcast of rank 0's index into every other rank's device buffers, bracketed by barriers.
+    -> (this rank's replica, seconds, config entries).  A failure fails the run (no silent per-rank rebuild: that curve would
+    not exercise the replication path)."""
+    job.sync()
+    job.barrier()
+    t0 = time.time()
+    hnsw = idd.replicate_index(hnsw, builder, src=0)
+    job.sync()
+    job.barrier()
+    t_rep = time.time() - t0
+    rep_bytes = idd.device_buffer_bytes(hnsw)
+    rep = {"replicate_bytes": rep_bytes, "replicate_GBps_per_destination": round(rep_bytes / max(t_rep, 1e-9) / 1e9, 2),
+           "replicate_note": "one broadcast tree over xGMI (7 links x ~153 GB/s per GPU); seconds include the first RCCL call's set-up"}
+    return hnsw, t_rep, rep
+
+
+def phase_queries(job, idd, nq_total, dim):
+    """Held-out draws, seed+1, generated identically on every rank; rank r keeps its contiguous block of the global batch."""
+    d_q_all = synth(job.torch, nq_total, dim, 123456790, job.dev)
+    lo, hi = idd.shard_range(nq_total, job.rank, job.world)
+    d_q = d_q_all[lo:hi].contiguous()
+    return d_q, lo, hi
+
+
+class Runner:
+    """The step: one pass of Hnsw::search over this rank's resident batch, results into resident buffers."""
+
+    def __init__(self, job, ida, hnsw, d_q):
+        self.job, self.ida, self.hnsw, self.d_q, self.nq = job, ida, hnsw, d_q, int(d_q.shape[0])
+        self.search = ida.Search()
+
+    def alloc_out(self, ef, nq=None):
+        torch, dev, nq = self.job.torch, self.job.dev, self.nq if nq is None else nq
+        return (torch.empty(nq, ef, dtype=torch.int32, device=dev), torch.empty(nq, ef, dtype=torch.float32, device=dev),
+                torch.empty(nq, dtype=torch.int32, device=dev), torch.empty(nq, 3, dtype=torch.int32, device=dev))
+
+    def run(self, outs, s=None, d_q=None):
+        pid, dd, cnt, ctr = outs
+        q = self.d_q if d_q is None else d_q
+        if int(q.shape[0]) == 0:
+            return                                           # more ranks than queries: this rank's block is empty
+        self.hnsw.search_batch_device(s or self.search, q.data_ptr(), int(q.shape[0]), pid.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
+                                      ctr.data_ptr(), self.job.stream())
+
+
+def phase_choose_ef(job, r, args, cfgd, k):
+    """Exact ground truth for the head of this rank's block (scan with the same canonical distance), then the smallest ef_search
+    of the ladder that reaches the recall target.  -> (chosen, recall, sweep, sample_out, gtq)"""
+    hnsw, nq = r.hnsw, r.nq
+    gt_req = cfgd["gtq"] if args.gt_queries < 0 else args.gt_queries
+    gtq = min(gt_req or nq, nq)
+    truth = hnsw.bruteforce(r.d_q[:gtq].cpu().numpy(), k)[0] if gtq else np.zeros((0, k), np.uint32)
+    sweep, sample_out = {}, {}
+    pq = min(args.parity_queries, nq)
+    chosen, recall, last = None, 0.0, (args.ef or 100, 0.0)
+    for ef in ([args.ef] if args.ef else [100, 200, 400, 800]):
+        if chosen is not None and ef > 200:
+            break                                   # 100 and 200 are always on the curve; beyond only while the target is missed
+        hnsw.set_ef_search(ef)
+        outs = r.alloc_out(ef)
+        r.run(outs)
+        job.sync()
+        if nq:
+            r.search.check_status()
+        got = outs[0][:gtq, :k].cpu().numpy().astype(np.uint32)
+        rec = float(np.mean([len(set(got[i].tolist()) & set(truth[i].tolist())) / k for i in range(gtq)])) if gtq else 1.0
+        sweep[str(ef)] = round(rec, 4)
+        sample_out[ef] = tuple(t[:pq].cpu().numpy() for t in outs)      # what the oracle is compared with below
+        if chosen is None and (rec >= args.recall_target or args.ef):
+            chosen, recall = ef, rec
+        last = (ef, rec)
+        del outs
+    if chosen is None:
+        chosen, recall = last
+    return chosen, recall, sweep, sample_out, gtq
+
+
+def phase_timed(job, r, outs, warmup, steps):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides; the MAX over ranks."""
+    for _ in range(warmup):
+        r.run(outs)
+    job.sync()
+    job.barrier()
+    job.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.run(outs)
+    job.sync()
+    job.barrier()
+    job.sync()
+    elapsed = time.perf_counter() - t0
+    elapsed = float(job.reduce(elapsed, job.torch.float64, "MAX"))
+    if r.nq:
+        r.search.check_status()
+    return elapsed
+
+
+def answers_digest(arrays):
+    """63 bits over ids + distance bits + counts + work counters (fits a signed int64 tensor)"""
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return int.from_bytes(h.digest(), "little") >> 1
+
+
+def phase_replica_check(job, ida, hnsw, nq_total, dim, ef):
+    """A bad broadcast must fail loudly.  Every rank answers the SAME sample (the head of the global batch) on its own replica;
+    rank 0's answers are the yardstick (and are themselves held against the CPU oracle afterwards): one digest is broadcast and
+    compared on every rank, and EVERY rank leaves with SystemExit when any replica disagrees.
+    -> (replica_check object, d_sample, the sample's answers as numpy arrays)"""
+    torch = job.torch
+    rs_n = min(512, nq_total)
+    d_sample = synth(torch, nq_total, dim, 123456790, job.dev)[:rs_n].contiguous()
+    hnsw.set_ef_search(ef)                       # (the result buffers below are ef wide)
+    r = Runner(job, ida, hnsw, d_sample)
+    so = r.alloc_out(ef)
+    r.run(so)
+    job.sync()
+    r.search.check_status()
+    sample_np = [t.cpu().numpy() for t in so]
+    mine = answers_digest(sample_np)
+    ref = job.bcast_i64(mine, src=0)
+    same = int(job.reduce(1 if ref == mine else 0, torch.int32, "MIN"))
+    if not same:
+        raise SystemExit(f"rank {job.rank}: replica answers differ from rank 0's on the {rs_n}-query sample (this rank's digest {mine:#x}, "
+                         f"rank 0's {ref:#x}): a replicated index is not the built one")
+    return {"queries": rs_n, "all_ranks_identical_to_rank0": True, "digest": f"{mine:#x}"}, d_sample, sample_np
+
+
+def oracle_equals(o, pid, dd, cnt, ctr):
+    return bool(np.array_equal(o.pid, pid.astype(np.uint32)) and np.array_equal(o.dist.view(np.uint32), dd.view(np.uint32))
+                and np.array_equal(o.count, cnt.astype(np.uint32)) and np.array_equal(o.counters, ctr.astype(np.uint32)))
+
+
+def wait_for_peers(pids, timeout=90.0):
+    """Rank 0, after destroy_process_group: wait until the other ranks' processes are gone (their GPUs and HIP contexts with them)."""
+    def running(pid):
+        try:
+            return open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0] != "Z"    # a zombie holds no GPU
+        except OSError:
+            return False
+
+    t0 = time.time()
+    alive = [p for p in pids if p != os.getpid()]
+    while alive and time.time() - t0 < timeout:
+        alive = [p for p in alive if running(p)]
+        if alive:
+            time.sleep(0.2)
+    return not alive, round(time.time() - t0, 2)
+
+
+def run_bench(job, args):
+    """The whole measurement on one rank.  -> the output object on rank 0, None elsewhere."""
+    torch, dist = job.torch, job.dist
+    rank, world = job.rank, job.world
+    cfgd = CONFIGS[args.config]
+
+    import instant_distance_amd as ida
+    from instant_distance_amd import dist as idd
+
+    n, dim, k = args.n or cfgd["n"], args.dim or cfgd["dim"], args.k
+    nq_cfg = args.nq or cfgd["nq"]
+    split = cfgd["split"]
+    nq_total = nq_cfg if split else nq_cfg * world
+    builder = ida.Builder().max_batch(args.max_batch).device(job.local_rank)
+
+    # ---- data + build (rank 0), replicate ----
+    hnsw, d_pts, build = (None, None, {})
+    if rank == 0:
+        hnsw, d_pts, build = phase_build(job, ida, builder, n, dim)
+    t_rep, replication, rep = 0.0, "single GPU", {}
+    if job.multi:
+        hnsw, t_rep, rep = phase_replicate(job, idd, hnsw, builder)
+        replication = f"rank 0 built, {dist.get_backend()} broadcast of points/zero/upper device buffers"
+
+    d_q, lo, hi = phase_queries(job, idd, nq_total, dim)
+    nq = hi - lo
+    r = Runner(job, ida, hnsw, d_q)
+    search = r.search
+
+    if args.traffic_child:
+        # profiled child of measure_traffic(): the same index, the same queries; one calibration gather with a known byte count
+        # (every row of the index once, in random order, through the 8-lanes-per-row loads of the walk), then full batches
+        hnsw.set_ef_search(args.ef or 100)
+        outs = r.alloc_out(args.ef or 100)
+        perm = torch.randperm(n, device=job.dev).to(torch.int32).cpu().numpy().astype(np.uint32).reshape(1, n)
+        hnsw.distances(d_q[:1].cpu().numpy(), perm)
+        print("known_read_bytes_per_launch", n * hnsw.info().row_stride * 4 + n * 4, flush=True)
+        for _ in range(2):
+            r.run(outs)
+        job.sync()
+        search.check_status()
+        return None
+
+    # ---- ground truth + ef choice; every rank must time the same ef ----
+    chosen, recall, sweep, sample_out, gtq = phase_choose_ef(job, r, args, cfgd, k)
+    chosen = int(job.reduce(chosen, torch.int64, "MAX"))
+    hnsw.set_ef_search(chosen)
+    outs = r.alloc_out(chosen)
+
+    # ---- timed region ----
+    elapsed = phase_timed(job, r, outs, args.warmup, args.steps)
+
+    replica_check, d_sample, sample_np = None, None, None
+    if job.multi:
+        replica_check, d_sample, sample_np = phase_replica_check(job, ida, hnsw, nq_total, dim, chosen)
+
+    out = None
+    if rank == 0:
+        out = rank0_report(job, args, cfgd, ida, r, outs, hnsw, d_pts, build, dict(
+            n=n, dim=dim, k=k, nq=nq, nq_total=nq_total, split=split, chosen=chosen, recall=recall, sweep=sweep, sample_out=sample_out,
+            gtq=gtq, elapsed=elapsed, t_rep=t_rep, replication=replication, rep=rep, replica_check=replica_check, d_sample=d_sample,
+            sample_np=sample_np))
+    return out
+
+
+def rank0_report(job, args, cfgd, ida, r, outs, hnsw, d_pts, build, m):
+    """Rank 0 after the timed region: the JSON line's objects (roofline from the kernel's own counters and HIP events, the
+    reference's scalar call pattern, the host-pointer rate, and the CPU oracle as checker / baseline)."""
+    torch, world = job.torch, job.world
+    n, dim, k, nq, nq_total, chosen = m["n"], m["dim"], m["k"], m["nq"], m["nq_total"], m["chosen"]
+    search, d_q, run, alloc_out = r.search, r.d_q, r.run, r.alloc_out
+    sample_out, replica_check = m["sample_out"], m["replica_check"]
+    elapsed = m["elapsed"]
+    ms_per_step = elapsed / args.steps * 1e3
+    value = nq_total / (elapsed / args.steps)
+    kt = search.kernel_times_ms(args.steps)
+    ctr = outs[3].cpu().numpy().astype(np.int64)
+    launch_bytes = int((ctr[:, 0] * 4 * dim + ctr[:, 1] * 256 + ctr[:, 2] * 128 + 8 * chosen).sum())
+    kernel_ms = float(kt.mean()) if len(kt) else float("nan")
+    achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+    # HBM bytes per launch: separate `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` child passes over this same command (PMC passes
+    # cannot run inside the timed process); the newest committed result for the same workload is quoted beside it
+    quoted, quoted_src, mall = None, None, None
+    import glob
+    for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):   # newest round first
+        try:
+            tj = json.load(open(tp))
+            if tj.get("config", "C3") != args.config:
+                continue
+            quoted = tj.get("search_kernel_hbm_bytes_per_launch")
+            mall = tj.get("mall")
+            quoted_src = os.path.relpath(tp, ROOT) + " (separate PMC passes of this command, not this run)"
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    traffic, traffic_why = (None, "skipped (--no-traffic, N > 1, or a 10M-point configuration)")
+    if not args.no_traffic and world == 1 and job.cuda and n * dim <= 2_000_000_000:
+        traffic, traffic_why = measure_traffic(args, n, dim, nq, chosen)
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic["bytes_per_launch"] if traffic else None,
+                "traffic_over_algorithmic": round(traffic["bytes_per_launch"] / launch_bytes, 4) if traffic else None,
+                "traffic_in_run": traffic if traffic else {"skipped": traffic_why},
+                "traffic_quoted": quoted, "traffic_source": quoted_src,
+                "mall_note": "FETCH_SIZE counts the L2's fabric-side requests: Infinity-Cache (MALL) hits are inside it, so "
+                             "'traffic' is fabric bytes, an upper bound of DRAM bytes; that is how an algorithmic rate can "
+                             "exceed the 6.29 TB/s streaming-copy rate of the HBM stacks", "mall": mall,
+                "kernel": "search_kernel", "kernel_ms_avg": round(kernel_ms, 3),
+                "alg_bytes_per_launch": launch_bytes, "alg_bytes_per_query": round(launch_bytes / max(nq, 1)),
+                "n_dist_per_query": round(float(ctr[:, 0].mean()), 1) if nq else 0.0, "n_exp0_per_query": round(float(ctr[:, 1].mean()), 1) if nq else 0.0,
+                "n_expU_per_query": round(float(ctr[:, 2].mean()), 1) if nq else 0.0}
+
+    # the reference's own call pattern: one query per call (`Hnsw::search`).  Outside the timed region.
+    lat_n = min(32, nq)
+    for i in range(lat_n):
+        run(outs, d_q=d_q[i:i + 1])
+    job.sync()
+    single = {"gpu_kernel_ms_median": round(float(np.median(search.kernel_times_ms(lat_n))), 4) if lat_n else None, "queries": lat_n,
+              "note": "nq = 1 per launch (the reference's scalar Hnsw::search); cpu = one oracle thread"}
+    # the C ABI's host-pointer call: queries from host memory, results back to host memory (PCIe inclusive), never `value`
+    q_host = d_q.cpu().numpy()
+    hnsw.search_batch(q_host[:1], search)
+    t0 = time.perf_counter()
+    for i in range(lat_n):
+        hnsw.search_batch(q_host[i:i + 1], search)
+    single["gpu_wall_ms_host_pointers"] = round((time.perf_counter() - t0) / max(lat_n, 1) * 1e3, 4)
+    # T host threads, one Search each, scalar calls on one shared index (core/lib.rs:352-356)
+    thr = {}
+    for T in [int(x) for x in args.threads.split(",") if x]:
+        thr[str(T)] = {"gpu_calls_per_s": round(scalar_calls(hnsw, ida, q_host, T, max(200, 1600 // T)), 1),
+                       "gpu_kernel_ms_mean": None if scalar_calls.kernel_ms is None else round(scalar_calls.kernel_ms, 4)}
+    single["threads"] = thr
+    hnsw.search_batch(q_host, search)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        res_host = hnsw.search_batch(q_host, search, counters=True)
+    pcie = {"qps": round(nq * 3 / (time.perf_counter() - t0), 1),
+            "note": f"idist_search_batch with host pointers: {nq * dim * 4 >> 20} MB of queries in, {nq * chosen * 8 >> 20} MB of results out per call, pageable memory"}
+    run(outs)                      # restore the full-batch outputs the checks below read
+    job.sync()
+    assert np.array_equal(res_host.pid, outs[0].cpu().numpy().astype(np.uint32))
+    del res_host
+
+    checks = None
+    if args.check:
+        pid_t, dd_t, cnt_t = outs[0], outs[1], outs[2]
+        srt = torch.sort(pid_t, dim=1).values
+        outs2 = alloc_out(chosen)
+        run(outs2, ida.Search())                                     # a fresh Search: same answers (idempotence)
+        job.sync()
+        ns = min(64, n)
+        self_q = d_pts[:ns].cpu().numpy()
+        sres = hnsw.search_batch(self_q, ida.Search())                # narrow batch: four waves per query
+        checks = {"count_is_ef": bool((cnt_t == min(chosen, n)).all().item()),
+                  "sorted_nearest_first": bool((dd_t[:, :-1] <= dd_t[:, 1:]).all().item()),
+                  "ids_unique_per_query": bool((srt[:, 1:] != srt[:, :-1]).all().item()),
+                  "idempotent": bool(torch.equal(outs2[0], pid_t) and torch.equal(outs2[1], dd_t)),
+                  "self_query_first_at_distance_0": bool(np.array_equal(sres.pid[:, 0], np.arange(ns)) and np.all(sres.distance[:, 0] == 0))}
+        del outs2, srt
+
+    cpu, parity = None, None
+    need_gb = (n * dim * 4 + n * 256 * 2) / 2**30 + 4
+    try:
+        avail_gb = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) / 2**20
+    except Exception:  # noqa: BLE001
+        avail_gb = 1e9
+    oix = None
+    if not args.no_cpu_baseline and avail_gb < need_gb:
+        parity = {"skipped": f"the oracle needs the points on the host: {need_gb:.0f} GB, {avail_gb:.0f} GB available"}
+    elif not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        zero, layers = hnsw.into_parts()
+        pts_h = d_pts.cpu().numpy()
+        # (the oracle reads the arrays in place: a second host copy of 10M x 768 points would be another 31 GB)
+        oix = po.Index.from_arrays(pts_h, zero, layers, po.default_config(ef_search=chosen), borrow=True)
+        cores = effective_cores()
+    if oix is not None and replica_check is not None:
+        # the yardstick of the replica check is itself held against the oracle: rank 0's answers for the sample == the oracle's on
+        # the exported graph
+        o = oix.search(m["d_sample"].cpu().numpy(), threads=cores)
+        ok = oracle_equals(o, *m["sample_np"])
+        replica_check["rank0_identical_to_oracle"] = ok
+        if not ok:
+            raise SystemExit("rank 0: GPU answers for the replica-check sample differ from the CPU oracle's on the exported graph")
+        if world > 1:
+            parity = {"queries": replica_check["queries"], f"ef{chosen}": ok, "all_identical": ok,
+                      "note": "N > 1: rank 0's answers for the replica-check sample against the oracle on the exported graph"}
+    if oix is not None and world == 1:
+        # (CPU timing on rank 0 at N = 1 only)
+        if checks is not None:
+            valid = zero != 0xFFFFFFFF
+            checks["layer_sizes_match_reference"] = [l.shape[0] for l in layers] == po.layer_sizes(n)[1:]
+            checks["rows_prefix_valid"] = bool(np.all(valid[:, :-1] >= valid[:, 1:]))
+            checks["row_ids_in_range"] = bool(np.all(zero[valid] < n))
+            checks["min_degree"] = int(valid.sum(1).min())
+            checks["no_self_links"] = bool(not np.any(zero == np.arange(n, dtype=np.uint32)[:, None]))
+            del valid
+        q_h = q_host
+        pq = min(args.parity_queries, nq)
+        # ---- parity: ids / order / counts / distance bits / work counters of a query sample, per ef ----
+        parity = {"queries": pq}
+        for ef, got in sorted(sample_out.items()):
+            oix.set_ef_search(ef)
+            parity[f"ef{ef}"] = oracle_equals(oix.search(q_h[:pq], threads=cores), *got)
+        parity["all_identical"] = all(v for k_, v in parity.items() if k_.startswith("ef"))
+        oix.set_ef_search(chosen)
+        # bounded sample: ~10-30 core-seconds of CPU work; best of 3 passes (thread start-up noise)
+        probe = min(nq, 8 * cores)
+        t0 = time.perf_counter(); oix.search(q_h[:probe], threads=cores); tp_ = time.perf_counter() - t0
+        core_s_per_q = tp_ * min(cores, probe) / probe
+        sample = args.cpu_sample or int(min(nq, max(probe, 20.0 / max(core_s_per_q, 1e-6))))
+        tc = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter(); ores = oix.search(q_h[:sample], threads=cores); tc = min(tc, time.perf_counter() - t0)
+        same = bool(np.array_equal(ores.pid, outs[0][:sample].cpu().numpy().astype(np.uint32)))
+        same_all = oracle_equals(ores, *[t[:sample].cpu().numpy() for t in outs])
+        t0 = time.perf_counter(); oix.search(q_h[:200], threads=1)
+        single["cpu_ms_per_query_one_thread"] = round((time.perf_counter() - t0) / min(200, nq) * 1e3, 4)
+        for T, row in thr.items():
+            nn = min(nq, max(200, 100 * int(T)))
+            t0 = time.perf_counter(); oix.search(q_h[:nn], threads=int(T))
+            row["cpu_oracle_calls_per_s"] = round(nn / (time.perf_counter() - t0), 1)
+        # build baseline: the oracle's threaded build (per-layer parallel-for + per-node locks, the rayon path of
+        # core/lib.rs:316-318) on a PREFIX of the same points — the rate falls with n, so this flatters the CPU
+        nb_ = min(n, cfgd["cpu_build"] if args.cpu_build_sample < 0 else args.cpu_build_sample)
+        if nb_:
+            t0 = time.perf_counter(); po.Index.build(pts_h[:nb_], po.default_config(), threads=cores); tb_ = time.perf_counter() - t0
+            build["cpu_baseline"] = {"value": round(nb_ / tb_, 1), "unit": "points/s", "cores": cores, "kind": "port",
+                                     "sample": f"first {nb_} of the {n} points, {cores} threads (prefix: optimistic for the CPU)",
+                                     "seconds": round(tb_, 2)}
+            build["gpu_over_cpu"] = round(build["points_per_s"] / build["cpu_baseline"]["value"], 1)
+        cpu = {"value": round(sample / tc, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+               "sample": f"first {sample} of the {nq} queries, same graph, ef_search={chosen}, {cores} threads = the "
+                         f"container's CPU quota ({os.cpu_count()} logical CPUs visible) "
+                         "(C oracle = restated reference, not the Rust crate)",
+               "seconds": round(tc, 2), "ids_identical_to_gpu": same,
+               "ids_distance_bits_counts_and_work_counters_identical_to_gpu": same_all}
+
+    recall = m["recall"]
+    out = {"commit": source_stamp(),
+           "metric": f"queries/sec @ recall@10>=0.95, {'1M' if n == 1_000_000 else n}x{dim}-d f32; index build points/sec",
+           "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if m["split"] else "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{cfgd['what']} — {n}x{dim}-d f32 fastText-shape synthetic (32-d latent, L2-normalised), "
+                                  f"Builder::build on GPU + {nq}-query Hnsw::search batch per GPU, k={k}",
+                      "name": args.config, "n": n, "dim": dim, "queries_per_gpu": nq, "k": k, "ef_search": chosen,
+                      "recall_at_10": round(recall, 4), "recall_target": args.recall_target,
+                      "recall_target_met": bool(recall >= args.recall_target), "recall_queries": m["gtq"],
+                      "ef_sweep_recall": m["sweep"], "parallelism": f"query-shard x{world}, index replicated",
+                      "replication": m["replication"], "replicate_seconds": round(m["t_rep"], 3), **m["rep"]},
+           "build": build, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "single_query": single,
+           "pcie_inclusive": pcie}
+    if replica_check is not None:
+        out["replica_check"] = replica_check
+    if checks is not None:
+        out["checks"] = checks
+    if cpu:
+        out["gpu_over_cpu"] = round(value / cpu["value"], 2)
+    return out
+
+
+def inproc_rccl_child(args, world, n, dim, chosen):
+    """The C ABI's own replication (idist_replicate_rccl: ONE process, ncclCommInitAll over the devices, one grouped ncclBroadcast
+    per buffer) next to the torch.distributed path.  A child process: whatever RCCL does there (a hang, a crash) costs the line
+    nothing but this entry."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-child", str(world), "--config", args.config, "--n", str(n),
+                            "--dim", str(dim), "--ef", str(chosen), "--max-batch", str(args.max_batch)], capture_output=True, text=True, timeout=420)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-300:]}
+    except Exception as e:  # noqa: BLE001
+        return {"skipped": repr(e)[:200]}
+
+
+def main():
+    args = parse_args()
     cfgd = CONFIGS[args.config]
 
     import torch
@@ -279,387 +788,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # Launched by torch.distributed.run (RANK + MASTER_ADDR in the environment): one rank per GPU over RCCL — also at
+    # --nproc-per-node 1, where the same replicate / agree / barrier / digest lines run with a world of one.
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-
-    import instant_distance_amd as ida
-    from instant_distance_amd import dist as idd
-
-    n, dim, k = args.n or cfgd["n"], args.dim or cfgd["dim"], args.k
-    nq_cfg = args.nq or cfgd["nq"]
-    split = cfgd["split"]
-    nq_total = nq_cfg if split else nq_cfg * world
-    builder = ida.Builder().max_batch(args.max_batch).device(local_rank)
-
-    # ---- data + build (rank 0), replicate ----
-    build = {}
-    hnsw = None
-    d_pts = None
-    if rank == 0:
-        d_pts = synth(torch, n, dim, 123456789, dev)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        hnsw = ida.Hnsw.from_device_points(d_pts.data_ptr(), n, dim, builder)
-        t_build = time.time() - t0
-        st = hnsw.build_stats()
-        build = {"points_per_s": round(n / st.seconds, 1), "device_seconds": round(st.seconds, 3),
-                 "wall_seconds": round(t_build, 3), "ef_construction": 100, "batches": int(st.n_batches),
-                 "n_dist": int(st.n_dist), "n_sel_pairs": int(st.n_sel_pairs), "n_updates": int(st.n_updates),
-                 "n_updates_memoised": int(st.n_updates_fast), "n_updates_full": int(st.n_updates_full),
-                 "n_heur_rows": int(st.n_heur_rows),
-                 "n_sel_pairs_note": "candidate pairs of select_heuristic decided here (by the Gram-matrix filter, a memoised "
-                                     "verdict or the canonical distance) — NOT the reference's early-exit count of distance calls"}
-        # Bytes the build's algorithm moves AS EXECUTED HERE: the descents (B_q with ef_construction on the partial
-        # graph), every point row fetched for select_heuristic / the neighbour re-selections (n_heur_rows; pairwise
-        # reuse is on chip, memoised verdicts fetch nothing), and the adjacency rows read + rewritten.
-        ab = int(st.n_dist * 4 * dim + st.n_exp0 * 256 + st.n_expU * 128 + st.n_heur_rows * 4 * dim
-                 + st.n_updates * 512 + n * 256)
-        build["roofline"] = {"bound": "hbm", "achieved": round(ab / st.seconds / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": round(ab / st.seconds / 1e9 / HBM_PEAK_GBPS, 4), "alg_bytes": ab,
-                             "note": "all build kernels together over the build's device time; per-kernel PMC bytes: profiles/"}
-    t_rep = 0.0
-    replication = "single GPU"
-    rep = {}
-    if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.time()
-        # RCCL broadcast into the replicas' device buffers; a failure fails the run (no silent per-rank rebuild:
-        # that curve would not exercise the replication path)
-        hnsw = idd.replicate_index(hnsw, builder, src=0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t_rep = time.time() - t0
-        replication = "rank 0 built, RCCL broadcast of points/zero/upper device buffers"
-        bufs = idd.device_views(hnsw, dev)
-        rep_bytes = int(sum(t.numel() for t in bufs if t is not None))
-        rep = {"replicate_bytes": rep_bytes, "replicate_GBps_per_destination": round(rep_bytes / max(t_rep, 1e-9) / 1e9, 2),
-               "replicate_note": "one broadcast tree over xGMI (7 links x ~153 GB/s per GPU); seconds include the first RCCL call's set-up"}
-
-    # ---- queries: held-out draws, seed+1; rank r takes its contiguous block of the global batch ----
-    d_q_all = synth(torch, nq_total, dim, 123456790, dev)
-    lo, hi = idd.shard_range(nq_total, rank, world)
-    d_q = d_q_all[lo:hi].contiguous()
-    nq = hi - lo
-    del d_q_all
-    search = ida.Search()
-
-    def alloc_out(ef):
-        return (torch.empty(nq, ef, dtype=torch.int32, device=dev), torch.empty(nq, ef, dtype=torch.float32, device=dev),
-                torch.empty(nq, dtype=torch.int32, device=dev), torch.empty(nq, 3, dtype=torch.int32, device=dev))
-
-    def run(outs, s=None):
-        pid, dd, cnt, ctr = outs
-        hnsw.search_batch_device(s or search, d_q.data_ptr(), nq, pid.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
-                                 ctr.data_ptr(), torch.cuda.current_stream().cuda_stream)
-
+    job = Job(torch, rank, world, local_rank, dev, dist)
+    out = run_bench(job, args)
     if args.traffic_child:
-        # profiled child of measure_traffic(): the same index, the same queries; one calibration gather with a known byte count
-        # (every row of the index once, in random order, through the 8-lanes-per-row loads of the walk), then full batches
-        hnsw.set_ef_search(args.ef or 100)
-        outs = alloc_out(args.ef or 100)
-        perm = torch.randperm(n, device=dev).to(torch.int32).cpu().numpy().astype(np.uint32).reshape(1, n)
-        hnsw.distances(d_q[:1].cpu().numpy(), perm)
-        print("known_read_bytes_per_launch", n * hnsw.info().row_stride * 4 + n * 4, flush=True)
-        for _ in range(2):
-            run(outs)
-        torch.cuda.synchronize()
-        search.check_status()
         return
-
-    # ---- ground truth (exact scan with the same canonical distance) + ef choice ----
-    gt_req = cfgd["gtq"] if args.gt_queries < 0 else args.gt_queries
-    gtq = min(gt_req or nq, nq)
-    truth, _ = hnsw.bruteforce(d_q[:gtq].cpu().numpy(), k)
-    sweep, sample_out = {}, {}
-    pq = min(args.parity_queries, nq)
-    chosen, recall = None, 0.0
-    for ef in ([args.ef] if args.ef else [100, 200, 400, 800]):
-        if chosen is not None and ef > 200:
-            break                                   # 100 and 200 are always on the curve; beyond only while the target is missed
-        hnsw.set_ef_search(ef)
-        outs = alloc_out(ef)
-        run(outs)
-        torch.cuda.synchronize()
-        search.check_status()
-        got = outs[0][:gtq, :k].cpu().numpy().astype(np.uint32)
-        rec = float(np.mean([len(set(got[i].tolist()) & set(truth[i].tolist())) / k for i in range(gtq)]))
-        sweep[str(ef)] = round(rec, 4)
-        sample_out[ef] = tuple(t[:pq].cpu().numpy() for t in outs)      # what the oracle is compared with below
-        if chosen is None and (rec >= args.recall_target or args.ef):
-            chosen, recall = ef, rec
-        last = (ef, rec)
-        del outs
-    if chosen is None:
-        chosen, recall = last
-    if world > 1:   # every rank must time the same ef
-        t = torch.tensor([chosen], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        chosen = int(t.item())
-    hnsw.set_ef_search(chosen)
-    outs = alloc_out(chosen)
-
-    # ---- timed region ----
-    for _ in range(args.warmup):
-        run(outs)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run(outs)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    search.check_status()
-
-    # ---- N > 1: a bad broadcast must fail loudly.  Every rank answers the SAME sample (the head of the global batch) on its
-    # own replica; rank 0's answers are the yardstick (and are themselves checked against the CPU oracle below): one u64
-    # digest of ids + distance bits + counts + work counters is broadcast and compared on every rank.
-    replica_check = None
-    if world > 1:
-        rs_n = min(512, nq_total)
-        d_sample = synth(torch, nq_total, dim, 123456790, dev)[:rs_n].contiguous()
-        so = (torch.empty(rs_n, chosen, dtype=torch.int32, device=dev), torch.empty(rs_n, chosen, dtype=torch.float32, device=dev),
-              torch.empty(rs_n, dtype=torch.int32, device=dev), torch.empty(rs_n, 3, dtype=torch.int32, device=dev))
-        s2_ = ida.Search()
-        hnsw.search_batch_device(s2_, d_sample.data_ptr(), rs_n, so[0].data_ptr(), so[1].data_ptr(), so[2].data_ptr(), so[3].data_ptr(),
-                                 torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        s2_.check_status()
-        import hashlib
-        hsh = hashlib.blake2b(digest_size=8)
-        sample_np = [t.cpu().numpy() for t in so]
-        for arr in sample_np:
-            hsh.update(np.ascontiguousarray(arr).tobytes())
-        mine = int.from_bytes(hsh.digest(), "little") >> 1          # 63 bits: fits a signed int64 tensor
-        ref = torch.tensor([mine], dtype=torch.int64, device=dev)
-        dist.broadcast(ref, src=0)
-        same = torch.tensor([1 if int(ref.item()) == mine else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(same, op=dist.ReduceOp.MIN)
-        if not bool(same.item()):
-            raise SystemExit(f"rank {rank}: replica answers differ from rank 0's on the {rs_n}-query sample (digest {mine:#x} vs "
-                             f"{int(ref.item()):#x}): the replicated index is not the built one")
-        replica_check = {"queries": rs_n, "all_ranks_identical_to_rank0": True, "digest": f"{mine:#x}"}
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = nq_total / (elapsed / args.steps)
-        kt = search.kernel_times_ms(args.steps)
-        ctr = outs[3].cpu().numpy().astype(np.int64)
-        launch_bytes = int((ctr[:, 0] * 4 * dim + ctr[:, 1] * 256 + ctr[:, 2] * 128 + 8 * chosen).sum())
-        kernel_ms = float(kt.mean())
-        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch come from separate `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` passes over this same command
-        # (scripts/profile_bench.sh; PMC passes cannot run inside the timed process): nothing is measured in THIS run
-        # (`traffic` = null), the newest committed result for the same workload is quoted beside it
-        quoted, quoted_src, mall = None, None, None
-        import glob
-        for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):   # newest round first
-            try:
-                tj = json.load(open(tp))
-                if tj.get("config", "C3") != args.config:
-                    continue
-                quoted = tj.get("search_kernel_hbm_bytes_per_launch")
-                mall = tj.get("mall")
-                quoted_src = os.path.relpath(tp, ROOT) + " (separate PMC passes of this command, not this run)"
-                break
-            except Exception:  # noqa: BLE001
-                continue
-        traffic, traffic_why = (None, "skipped (--no-traffic, N > 1, or a 10M-point configuration)")
-        if not args.no_traffic and world == 1 and n * dim <= 2_000_000_000:
-            traffic, traffic_why = measure_traffic(args, n, dim, nq, chosen)
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic["bytes_per_launch"] if traffic else None,
-                    "traffic_over_algorithmic": round(traffic["bytes_per_launch"] / launch_bytes, 4) if traffic else None,
-                    "traffic_in_run": traffic if traffic else {"skipped": traffic_why},
-                    "traffic_quoted": quoted, "traffic_source": quoted_src,
-                    "mall_note": "FETCH_SIZE counts the L2's fabric-side requests: Infinity-Cache (MALL) hits are inside it, so "
-                                 "'traffic' is fabric bytes, an upper bound of DRAM bytes; that is how an algorithmic rate can "
-                                 "exceed the 6.29 TB/s streaming-copy rate of the HBM stacks", "mall": mall,
-                    "kernel": "search_kernel", "kernel_ms_avg": round(kernel_ms, 3),
-                    "alg_bytes_per_launch": launch_bytes, "alg_bytes_per_query": round(launch_bytes / nq),
-                    "n_dist_per_query": round(float(ctr[:, 0].mean()), 1), "n_exp0_per_query": round(float(ctr[:, 1].mean()), 1),
-                    "n_expU_per_query": round(float(ctr[:, 2].mean()), 1)}
-
-        # the reference's own call pattern: one query per call (`Hnsw::search`).  Outside the timed region.
-        lat_n = min(32, nq)
-        for i in range(lat_n):
-            hnsw.search_batch_device(search, d_q[i:i + 1].data_ptr(), 1, outs[0].data_ptr(), outs[1].data_ptr(),
-                                     outs[2].data_ptr(), outs[3].data_ptr(), torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        single = {"gpu_kernel_ms_median": round(float(np.median(search.kernel_times_ms(lat_n))), 4), "queries": lat_n,
-                  "note": "nq = 1 per launch (the reference's scalar Hnsw::search); cpu = one oracle thread"}
-        # the C ABI's host-pointer call: queries from host memory, results back to host memory (PCIe inclusive), never `value`
-        q_host = d_q.cpu().numpy()
-        hnsw.search_batch(q_host[:1], search)
-        t0 = time.perf_counter()
-        for i in range(lat_n):
-            hnsw.search_batch(q_host[i:i + 1], search)
-        single["gpu_wall_ms_host_pointers"] = round((time.perf_counter() - t0) / lat_n * 1e3, 4)
-        # T host threads, one Search each, scalar calls on one shared index (core/lib.rs:352-356)
-        thr = {}
-        for T in [int(x) for x in args.threads.split(",") if x]:
-            thr[str(T)] = {"gpu_calls_per_s": round(scalar_calls(hnsw, ida, q_host, T, max(200, 1600 // T)), 1),
-                           "gpu_kernel_ms_mean": None if scalar_calls.kernel_ms is None else round(scalar_calls.kernel_ms, 4)}
-        single["threads"] = thr
-        hnsw.search_batch(q_host, search)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            res_host = hnsw.search_batch(q_host, search, counters=True)
-        pcie = {"qps": round(nq * 3 / (time.perf_counter() - t0), 1),
-                "note": f"idist_search_batch with host pointers: {nq * dim * 4 >> 20} MB of queries in, {nq * chosen * 8 >> 20} MB of results out per call, pageable memory"}
-        run(outs)                      # restore the full-batch outputs the checks below read
-        torch.cuda.synchronize()
-        assert np.array_equal(res_host.pid, outs[0].cpu().numpy().astype(np.uint32))
-        del res_host
-
-        checks = None
-        if args.check:
-            pid_t, dd_t, cnt_t = outs[0], outs[1], outs[2]
-            srt = torch.sort(pid_t, dim=1).values
-            outs2 = alloc_out(chosen)
-            run(outs2, ida.Search())                                     # a fresh Search: same answers (idempotence)
-            torch.cuda.synchronize()
-            ns = min(64, n)
-            self_q = d_pts[:ns].cpu().numpy()
-            sres = hnsw.search_batch(self_q, ida.Search())                # narrow batch: four waves per query
-            checks = {"count_is_ef": bool((cnt_t == min(chosen, n)).all().item()),
-                      "sorted_nearest_first": bool((dd_t[:, :-1] <= dd_t[:, 1:]).all().item()),
-                      "ids_unique_per_query": bool((srt[:, 1:] != srt[:, :-1]).all().item()),
-                      "idempotent": bool(torch.equal(outs2[0], pid_t) and torch.equal(outs2[1], dd_t)),
-                      "self_query_first_at_distance_0": bool(np.array_equal(sres.pid[:, 0], np.arange(ns)) and np.all(sres.distance[:, 0] == 0))}
-            del outs2, srt
-
-        cpu, parity = None, None
-        need_gb = (n * dim * 4 + n * 256 * 2) / 2**30 + 4
-        try:
-            avail_gb = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) / 2**20
-        except Exception:  # noqa: BLE001
-            avail_gb = 1e9
-        if not args.no_cpu_baseline and world > 1 and avail_gb >= need_gb:
-            # N > 1: no CPU timing (rank 0 at N = 1 only), but the yardstick of the replica check is itself held against the
-            # oracle: rank 0's answers for the sample == the oracle's on the exported graph
-            from oracle import pyoracle as po
-            zero, layers = hnsw.into_parts()
-            oix = po.Index.from_arrays(d_pts.cpu().numpy(), zero, layers, po.default_config(ef_search=chosen), borrow=True)
-            o = oix.search(d_sample.cpu().numpy(), threads=effective_cores())
-            ok = bool(np.array_equal(o.pid, sample_np[0].astype(np.uint32)) and np.array_equal(o.dist.view(np.uint32), sample_np[1].view(np.uint32))
-                      and np.array_equal(o.count, sample_np[2].astype(np.uint32)) and np.array_equal(o.counters, sample_np[3].astype(np.uint32)))
-            replica_check["rank0_identical_to_oracle"] = ok
-            if not ok:
-                raise SystemExit("rank 0: GPU answers for the replica-check sample differ from the CPU oracle's on the exported graph")
-            parity = {"queries": replica_check["queries"], f"ef{chosen}": ok, "all_identical": ok,
-                      "note": "N > 1: rank 0's answers for the replica-check sample against the oracle on the exported graph"}
-            del oix, zero, layers
-        if not args.no_cpu_baseline and world == 1 and avail_gb < need_gb:
-            parity = {"skipped": f"the oracle needs the points on the host: {need_gb:.0f} GB, {avail_gb:.0f} GB available"}
-        elif not args.no_cpu_baseline and world == 1:
-            from oracle import pyoracle as po
-            zero, layers = hnsw.into_parts()
-            if checks is not None:
-                valid = zero != 0xFFFFFFFF
-                checks["layer_sizes_match_reference"] = [l.shape[0] for l in layers] == po.layer_sizes(n)[1:]
-                checks["rows_prefix_valid"] = bool(np.all(valid[:, :-1] >= valid[:, 1:]))
-                checks["row_ids_in_range"] = bool(np.all(zero[valid] < n))
-                checks["min_degree"] = int(valid.sum(1).min())
-                checks["no_self_links"] = bool(not np.any(zero == np.arange(n, dtype=np.uint32)[:, None]))
-                del valid
-            pts_h = d_pts.cpu().numpy()
-            # (the oracle reads the arrays in place: a second host copy of 10M x 768 points would be another 31 GB)
-            oix = po.Index.from_arrays(pts_h, zero, layers, po.default_config(ef_search=chosen), borrow=True)
-            cores = effective_cores()
-            q_h = q_host
-            # ---- parity: ids / order / counts / distance bits / work counters of a query sample, per ef ----
-            parity = {"queries": pq}
-            for ef, (g_pid, g_dd, g_cnt, g_ctr) in sorted(sample_out.items()):
-                oix.set_ef_search(ef)
-                o = oix.search(q_h[:pq], threads=cores)
-                parity[f"ef{ef}"] = bool(np.array_equal(o.pid, g_pid.astype(np.uint32)) and
-                                         np.array_equal(o.dist.view(np.uint32), g_dd.view(np.uint32)) and
-                                         np.array_equal(o.count, g_cnt.astype(np.uint32)) and
-                                         np.array_equal(o.counters, g_ctr.astype(np.uint32)))
-            parity["all_identical"] = all(v for k_, v in parity.items() if k_.startswith("ef"))
-            oix.set_ef_search(chosen)
-            # bounded sample: ~10-30 core-seconds of CPU work; best of 3 passes (thread start-up noise)
-            probe = min(nq, 8 * cores)
-            t0 = time.perf_counter(); oix.search(q_h[:probe], threads=cores); tp_ = time.perf_counter() - t0
-            core_s_per_q = tp_ * min(cores, probe) / probe
-            sample = args.cpu_sample or int(min(nq, max(probe, 20.0 / max(core_s_per_q, 1e-6))))
-            tc = 1e30
-            for _ in range(3):
-                t0 = time.perf_counter(); ores = oix.search(q_h[:sample], threads=cores); tc = min(tc, time.perf_counter() - t0)
-            same = bool(np.array_equal(ores.pid, outs[0][:sample].cpu().numpy().astype(np.uint32)))
-            same_all = bool(same and np.array_equal(ores.dist.view(np.uint32), outs[1][:sample].cpu().numpy().view(np.uint32))
-                            and np.array_equal(ores.count, outs[2][:sample].cpu().numpy().astype(np.uint32))
-                            and np.array_equal(ores.counters, outs[3][:sample].cpu().numpy().astype(np.uint32)))
-            t0 = time.perf_counter(); oix.search(q_h[:200], threads=1)
-            single["cpu_ms_per_query_one_thread"] = round((time.perf_counter() - t0) / min(200, nq) * 1e3, 4)
-            for T, row in thr.items():
-                nn = min(nq, max(200, 100 * int(T)))
-                t0 = time.perf_counter(); oix.search(q_h[:nn], threads=int(T))
-                row["cpu_oracle_calls_per_s"] = round(nn / (time.perf_counter() - t0), 1)
-            # build baseline: the oracle's threaded build (per-layer parallel-for + per-node locks, the rayon path of
-            # core/lib.rs:316-318) on a PREFIX of the same points — the rate falls with n, so this flatters the CPU
-            nb_ = min(n, cfgd["cpu_build"] if args.cpu_build_sample < 0 else args.cpu_build_sample)
-            if nb_:
-                t0 = time.perf_counter(); po.Index.build(pts_h[:nb_], po.default_config(), threads=cores); tb_ = time.perf_counter() - t0
-                build["cpu_baseline"] = {"value": round(nb_ / tb_, 1), "unit": "points/s", "cores": cores, "kind": "port",
-                                         "sample": f"first {nb_} of the {n} points, {cores} threads (prefix: optimistic for the CPU)",
-                                         "seconds": round(tb_, 2)}
-                build["gpu_over_cpu"] = round(build["points_per_s"] / build["cpu_baseline"]["value"], 1)
-            cpu = {"value": round(sample / tc, 1), "unit": "queries/s", "cores": cores, "kind": "port",
-                   "sample": f"first {sample} of the {nq} queries, same graph, ef_search={chosen}, {cores} threads = the "
-                             f"container's CPU quota ({os.cpu_count()} logical CPUs visible) "
-                             "(C oracle = restated reference, not the Rust crate)",
-                   "seconds": round(tc, 2), "ids_identical_to_gpu": same,
-                   "ids_distance_bits_counts_and_work_counters_identical_to_gpu": same_all}
-
-        out = {"commit": source_stamp(),
-               "metric": f"queries/sec @ recall@10>=0.95, {'1M' if n == 1_000_000 else n}x{dim}-d f32; index build points/sec",
-               "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if split else "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{cfgd['what']} — {n}x{dim}-d f32 fastText-shape synthetic (32-d latent, L2-normalised), "
-                                      f"Builder::build on GPU + {nq}-query Hnsw::search batch per GPU, k={k}",
-                          "name": args.config, "n": n, "dim": dim, "queries_per_gpu": nq, "k": k, "ef_search": chosen,
-                          "recall_at_10": round(recall, 4), "recall_target": args.recall_target,
-                          "recall_target_met": bool(recall >= args.recall_target), "recall_queries": gtq,
-                          "ef_sweep_recall": sweep, "parallelism": f"query-shard x{world}, index replicated",
-                          "replication": replication, "replicate_seconds": round(t_rep, 3), **rep},
-               "build": build, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "single_query": single,
-               "pcie_inclusive": pcie}
-        if replica_check is not None:
-            out["replica_check"] = replica_check
-        if checks is not None:
-            out["checks"] = checks
-        if cpu:
-            out["gpu_over_cpu"] = round(value / cpu["value"], 2)
-    if world > 1:
+    pids = None
+    if job.multi:
+        pids = job.gather_i64(os.getpid())
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if world > 1 and not args.no_inproc_rccl:
-            # The C ABI's own replication (idist_replicate_rccl: ONE process, ncclCommInitAll over the devices, one grouped
-            # ncclBroadcast per buffer) next to the torch.distributed path above.  Measured in a child process once the per-rank
-            # processes are gone and their GPUs are free again: whatever RCCL does there (a hang, a crash) costs this line
-            # nothing but the entry.
-            import subprocess
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-child", str(world), "--config", args.config, "--n", str(n),
-                                    "--dim", str(dim), "--ef", str(chosen), "--max-batch", str(args.max_batch)], capture_output=True, text=True, timeout=420)
-                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                out["config"]["replicate_rccl_in_process"] = json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-300:]}
-            except Exception as e:  # noqa: BLE001
-                out["config"]["replicate_rccl_in_process"] = {"skipped": repr(e)[:200]}
+        if job.multi and not args.no_inproc_rccl:
+            gone, waited = wait_for_peers(pids)
+            child = inproc_rccl_child(args, world, out["config"]["n"], out["config"]["dim"], out["config"]["ef_search"])
+            child["peer_ranks_exited_before_launch"] = gone
+            child["waited_for_peers_s"] = waited
+            out["config"]["replicate_rccl_in_process"] = child
         print(json.dumps(out), flush=True)
 
 

@@ -46,6 +46,13 @@ def device_views(hnsw: Hnsw, device):
     return out
 
 
+def device_buffer_bytes(hnsw: Hnsw) -> int:
+    """Bytes of the three device buffers a replication moves (points + zero layer + upper layers)."""
+    bufs = _capi.DeviceBuffers()
+    _capi.lib().check(_capi.lib().idist_index_device_buffers(hnsw._h, C.byref(bufs)))
+    return int(bufs.points_bytes + bufs.zero_bytes + bufs.upper_bytes)
+
+
 def _bcast_meta(meta: np.ndarray, src: int):
     import torch
     import torch.distributed as dist
@@ -74,6 +81,7 @@ def replicate_index(hnsw: Hnsw | None, builder: Builder, src: int = 0, chunk_byt
     if rank == src:
         info = hnsw.info()
         meta[0], meta[1], meta[2], meta[3] = info.n, info.dim, info.n_upper, info.ef_search
+        meta[4] = 1 if (hnsw.points.shape[1] == info.dim or info.n == 0) else 0     # does the source hold a host copy of the points?
         meta[8:8 + info.n_upper] = list(info.layer_len)[: info.n_upper]
     meta = _bcast_meta(meta, src)
     n, dim, n_upper, ef = int(meta[0]), int(meta[1]), int(meta[2]), int(meta[3])
@@ -112,6 +120,10 @@ def replicate_index(hnsw: Hnsw | None, builder: Builder, src: int = 0, chunk_byt
         return hnsw
 
     # host transport
+    if not int(meta[4]):
+        # (every rank sees the same flag: all of them stop here, none is left inside a broadcast)
+        raise RuntimeError("replicate_index over a host transport needs the source's host copy of the points: build with "
+                           "Hnsw.from_ordered_points, or pass host_points= to Hnsw.from_device_points")
     if rank == src:
         zero, layers = hnsw.into_parts()
         pts = np.ascontiguousarray(hnsw.points, dtype=np.float32)

@@ -64,3 +64,28 @@ def test_c5_full_size_properties_gpu():
     out = run_config("C5")
     assert_config(out, 10_000_000, 768, 65_536)
     assert len(out["checks"]) and out["config"]["ef_search"] in (100, 200, 400)
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_one_rank_gpu():
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the N > 1 control flow on the real backend with a world of one
+    (nccl init on the device, replicate_index over RCCL out of the library's device buffers, ef agreement, barriers around the timed
+    steps, replica digest + rank-0 oracle check, the --rccl-child process after the process group is gone).  Small index: what is
+    tested is that every one of those lines runs on hardware; tests/test_distributed_gloo.py runs them at world sizes 2 and 3."""
+    import socket
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C2", "--n", "50000", "--nq", "2000",
+           "--steps", "3", "--warmup", "1", "--threads", "", "--cpu-sample", "512", "--cpu-build-sample", "0", "--no-traffic", "--check"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["replication"].startswith("rank 0 built, nccl broadcast")
+    assert out["config"]["replicate_bytes"] >= 50000 * (128 * 4 + 256)
+    rc = out["replica_check"]
+    assert rc["all_ranks_identical_to_rank0"] and rc["rank0_identical_to_oracle"] and rc["queries"] == 512
+    child = out["config"]["replicate_rccl_in_process"]
+    assert child.get("last_replica_answers_identical_to_root") is True and child["peer_ranks_exited_before_launch"], child
+    assert out["parity"]["all_identical"] and out["cpu_baseline"]["ids_distance_bits_counts_and_work_counters_identical_to_gpu"]
+    assert all(v is True for k, v in out["checks"].items() if k != "min_degree")

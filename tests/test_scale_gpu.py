@@ -85,3 +85,37 @@ def test_search_parity_runtime_geometry_at_size_gpu(engine_loader, oracle, n, di
         assert np.array_equal(got.pid[:32, 0], np.arange(32)) and np.all(got.distance[:32, 0] == 0)   # stored points find themselves
     truth, _ = h.bruteforce(q[:512], 10)
     assert pc.recall_at(got.pid[:512], truth, 10) > 0.9
+
+
+@pytest.mark.gpu
+def test_search_parity_long_walks_ef_600_to_1000_gpu(engine_loader, oracle):
+    """ef_search in (512, 1024] in steady state, default policy (no environment knob): the sixteen-register-block merge of
+    `Search::push` (core/lib.rs:704-720) and the two-256-register-waves-per-SIMD layout the policy picks from ef 512 at 300-d.
+    200,000 x 300 fastText-shape, GPU build, the oracle searches the exported graph (core/lib.rs:598-614); wide batch (one wave
+    per query) and a 64-query narrow batch (four waves per query): ids, order, counts, distance bits, work counters."""
+    import os
+
+    for knob in ("IDIST_W2_EF", "IDIST_LATENCY_NQ", "IDIST_QUAD_NQ", "IDIST_VISITED", "IDIST_TAB_FORMAT", "IDIST_TAB_LOG2"):
+        assert knob not in os.environ, f"{knob} is set: this case pins the DEFAULT policy"
+    ida = engine_loader("gpu")
+    n, dim, nq = 200_000, 300, 2048
+    pts = fasttext_shape(n, dim, 21)
+    q = fasttext_shape(nq, dim, 22)
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder())
+    zero, layers = h.into_parts()
+    oix = oracle.Index.from_arrays(pts, zero, layers, oracle.default_config())
+    for ef in (600, 800, 1000, 1024, 513):
+        h.set_ef_search(ef)
+        oix.set_ef_search(ef)
+        want = oix.search(q, threads=16)
+        got = h.search_batch(q, ida.Search(), counters=True)                 # wide batch
+        pc.check_search_result(got, want)
+        assert np.all(got.count == ef) and np.all(got.distance[:, :-1] <= got.distance[:, 1:])
+        narrow = h.search_batch(q[:64], ida.Search(), counters=True)         # narrow batch
+        assert np.array_equal(narrow.pid, want.pid[:64]) and np.array_equal(narrow.counters, want.counters[:64])
+        assert np.array_equal(pc.bits(narrow.distance), pc.bits(want.dist[:64])) and np.array_equal(narrow.count, want.count[:64])
+        # device-pointer style reuse: the same Search answers a second ef-wide batch identically (steady state, not first use)
+        s = ida.Search()
+        a = h.search_batch(q[:1500], s, counters=True)
+        b = h.search_batch(q[:1500], s, counters=True)
+        assert np.array_equal(a.pid, b.pid) and np.array_equal(a.pid, want.pid[:1500]) and np.array_equal(b.counters, want.counters[:1500])
