@@ -244,7 +244,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS), help="BASELINE.json configuration (default C3, the metric's)")
-    ap.add_argument("--n", type=int, default=0, help="override the configuration's point count")
+    # (--points: torch.distributed.run's own parser rejects a bare `--n` after the script name as an ambiguous abbreviation)
+    ap.add_argument("--n", "--points", dest="n", type=int, default=0, help="override the configuration's point count")
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--nq", type=int, default=0, help="queries per GPU per step (C5: of the whole job)")
     ap.add_argument("--k", type=int, default=10)

@@ -36,6 +36,18 @@ using namespace idist;
 
 namespace {
 
+// Environment knobs.  The product library (libidist.so) reads three — IDIST_COMBINE, IDIST_SYNC, IDIST_KERNEL_EVENTS: host-side
+// behaviour an integrator may want to switch.  Every other IDIST_* knob exists for tests and A/B measurements and is compiled
+// into the test build (libidist_variants.so, -DIDIST_VARIANTS), the measurement build (-DIDIST_PROBE) and the CPU emulator only:
+// in the product test_env() is a constant nullptr, so the branches behind it fold away and no environment variable can change
+// which kernels run or which graph is built.
+#if defined(IDIST_VARIANTS) || defined(IDIST_PROBE) || defined(IDIST_EMU)
+inline const char* test_env(const char* name) { return getenv(name); }
+#else
+constexpr const char* test_env(const char*) { return nullptr; }
+#endif
+
+char g_err_anchor;                                       // (its address identifies this loaded library, see index_alloc)
 thread_local std::string g_err;
 thread_local struct idist_progress* g_watch = nullptr;   // armed by idist_progress_watch_next_build
 
@@ -202,7 +214,8 @@ struct idist_progress {
     unsigned long long total = 0;
 };
 
-// Knobs read from the environment (measurement / test only), sampled once per context or build — not per launch.
+// Knobs read from the environment (see test_env above: three in the product, the rest in the test / measurement builds),
+// sampled once per context or build — not per launch.
 struct Knobs {
     uint32_t latency_nq = 1024;   // IDIST_LATENCY_NQ: batches up to this many queries run the latency walk (0 = never)
     bool classic = false;         // IDIST_WALK=classic
@@ -225,20 +238,20 @@ struct Knobs {
                                       // workgroups per CU, one for 768-d rows; 0 = never)
     static Knobs from_env() {
         Knobs k;
-        if (const char* e = getenv("IDIST_EA")) k.ea = atoi(e);
-        if (const char* e = getenv("IDIST_W2_EF")) k.w2_ef = (uint32_t)strtoul(e, nullptr, 10);
-        if (const char* e = getenv("IDIST_LATENCY_NQ")) k.latency_nq = (uint32_t)strtoul(e, nullptr, 10);
-        if (const char* e = getenv("IDIST_QUAD_NQ")) k.quad_nq = (uint32_t)std::min<unsigned long>(strtoul(e, nullptr, 10), 0xFFFFFFFEul);
-        if (const char* e = getenv("IDIST_WALK")) k.classic = e[0] == 'c';      // (honoured by the test build only, see variants_check)
-        if (const char* e = getenv("IDIST_BLOOM")) k.bloom = e[0] != '0';
-        if (const char* e = getenv("IDIST_VISITED")) { k.vis_bitmap = e[0] == 'b'; k.vis_onchip = e[0] == 'o'; }
-        if (const char* e = getenv("IDIST_NO_ZERO_COPY")) k.no_zero_copy = e[0] != '0';
-        if (const char* e = getenv("IDIST_TAB_FORMAT")) { k.tab_ids = e[0] == 'i'; k.tab_q16 = e[0] == 'q'; }
+        if (const char* e = test_env("IDIST_EA")) k.ea = atoi(e);
+        if (const char* e = test_env("IDIST_W2_EF")) k.w2_ef = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char* e = test_env("IDIST_LATENCY_NQ")) k.latency_nq = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char* e = test_env("IDIST_QUAD_NQ")) k.quad_nq = (uint32_t)std::min<unsigned long>(strtoul(e, nullptr, 10), 0xFFFFFFFEul);
+        if (const char* e = test_env("IDIST_WALK")) k.classic = e[0] == 'c';      // (honoured by the test build only, see variants_check)
+        if (const char* e = test_env("IDIST_BLOOM")) k.bloom = e[0] != '0';
+        if (const char* e = test_env("IDIST_VISITED")) { k.vis_bitmap = e[0] == 'b'; k.vis_onchip = e[0] == 'o'; }
+        if (const char* e = test_env("IDIST_NO_ZERO_COPY")) k.no_zero_copy = e[0] != '0';
+        if (const char* e = test_env("IDIST_TAB_FORMAT")) { k.tab_ids = e[0] == 'i'; k.tab_q16 = e[0] == 'q'; }
         if (const char* e = getenv("IDIST_KERNEL_EVENTS")) k.events = e[0] != '0';
-        if (const char* e = getenv("IDIST_TIE_SPILL")) k.tie_spill_first = e[0] == '1';
+        if (const char* e = test_env("IDIST_TIE_SPILL")) k.tie_spill_first = e[0] == '1';
         if (const char* e = getenv("IDIST_SYNC")) k.sync_flag = e[0] != 's';
         if (const char* e = getenv("IDIST_COMBINE")) k.combine = e[0] != '0';
-        if (const char* e = getenv("IDIST_TAB_LOG2")) k.tab_log2 = std::min(13u, std::max(5u, (uint32_t)atoi(e)));
+        if (const char* e = test_env("IDIST_TAB_LOG2")) k.tab_log2 = std::min(13u, std::max(5u, (uint32_t)atoi(e)));
         return k;
     }
 };
@@ -311,7 +324,9 @@ idist_status index_alloc(uint32_t n, uint32_t dim, const idist_config* cfg, cons
     if (n == 0xFFFFFFFFu) return fail(IDIST_ERR_INVALID_ARG, "n must be < u32::MAX (core/lib.rs:256)");
     if (n_upper >= IDIST_MAX_LAYERS) return fail(IDIST_ERR_INVALID_ARG, "more than %u layers", IDIST_MAX_LAYERS);
     CHK(check_device(device));
-    static std::atomic<uint64_t> next_uid{1};
+    // uids are unique across the libraries of one process too (libidist.so and the test build libidist_variants.so share handles in
+    // tests/): the counter starts at a value derived from where THIS library was mapped
+    static std::atomic<uint64_t> next_uid{(((uint64_t)(uintptr_t)&g_err_anchor >> 12) << 28) | 1u};
     idist_index* ix = new idist_index();
     ix->uid = next_uid.fetch_add(1);
     ix->device = device;
@@ -394,7 +409,7 @@ uint32_t tie_capacity(const idist_config& cfg) { return g_tie_cap_msg = cfg.tie_
 // IDIST_WALK=classic names walks that only the test build holds (libidist_variants.so): say so instead of running
 // something else under that name
 idist_status variants_check(bool classic) {
-#ifndef IDIST_VARIANTS
+#if defined(IDIST_PROBE) && !defined(IDIST_VARIANTS)   // (the product cannot be asked: it reads no IDIST_WALK)
     if (classic) return fail(IDIST_ERR_UNSUPPORTED, "IDIST_WALK=classic selects a test-only variant of the walk: load libidist_variants.so (make -C instant-distance_amd/csrc variants)");
 #endif
     (void)classic;
@@ -475,7 +490,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     uint32_t fc = 8;
     if (generic_geo && smem_bytes_update(ix->L.nb, 4, 8) > tile_budget) fc = 4;
     uint32_t rt = 8;
-    if (const char* e = getenv("IDIST_BUILD_RT")) rt = (uint32_t)atoi(e);
+    if (const char* e = test_env("IDIST_BUILD_RT")) rt = (uint32_t)atoi(e);
     while (rt > 0 && smem_bytes_update(ix->L.nb, rt, fc) > tile_budget) rt--;
     size_t smemB = smem_bytes_update(ix->L.nb, rt, fc);
     if (smemB > tile_budget) {                                   // does not fit beside the descents: take what a CU alone allows
@@ -487,7 +502,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
 
     // step A2 tile: the new point's selected set (up to 64 rows) — it is not memory bound, so favour rows on chip
     uint32_t rt2 = 16;
-    if (const char* e = getenv("IDIST_BUILD_RT2")) rt2 = (uint32_t)atoi(e);
+    if (const char* e = test_env("IDIST_BUILD_RT2")) rt2 = (uint32_t)atoi(e);
     while (rt2 > 0 && smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction, fc) > tile_budget) rt2--;
     size_t smemA2 = smem_bytes_select(ix->L.nb, rt2, cfg.ef_construction, fc);
     if (smemA2 > tile_budget) {
@@ -506,7 +521,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     if (ext && smemX > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_construction need %zu B of LDS per wave with extend_candidates (> 64 KiB)", smemX);
     // step A2 on the matrix cores (Gram matrix of the candidates as a filter, idist_mfma.hpp) where it applies
     const bool a2_mfma = cfg.has_heuristic && cfg.metric == IDIST_METRIC_L2SQ && cfg.ef_construction <= 128 &&
-                         !(getenv("IDIST_BUILD_A2") && getenv("IDIST_BUILD_A2")[0] == 't');
+                         !(test_env("IDIST_BUILD_A2") && test_env("IDIST_BUILD_A2")[0] == 't');
     const size_t smemA2m = smem_bytes_select_mfma(ix->L.stride);
     uint32_t* d_vis = nullptr;
     uint64_t* d_tie_spill = nullptr;
@@ -527,10 +542,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // kept in two copies, copy k&1 receiving the state after step k.  Deterministic like the sequential schedule;
     // a new point then misses the last two steps' points (<= 1/16 of the graph) instead of the last one's.
     bool pipe = cap > 1 && cfg.has_heuristic;
-    if (const char* e = getenv("IDIST_BUILD_PIPELINE")) pipe = pipe && e[0] != '0';
+    if (const char* e = test_env("IDIST_BUILD_PIPELINE")) pipe = pipe && e[0] != '0';
     // the descents (8-12 waves per CU saturate their HBM stream) leave wave slots and LDS to the other stream
     uint32_t a_waves = tab16 ? 4u : 3u;
-    if (const char* e = getenv("IDIST_BUILD_A_WAVES")) a_waves = (uint32_t)std::min(8, std::max(1, atoi(e)));
+    if (const char* e = test_env("IDIST_BUILD_A_WAVES")) a_waves = (uint32_t)std::min(8, std::max(1, atoi(e)));
     // the descent's register budget (quotient set only): 256 registers per wave (two waves fit a SIMD: the update stream's
     // waves find room on every SIMD) or 512 (IDIST_BUILD_A_REGS=512, more rounds in flight per wave).  C3: 1.26 vs 1.29-1.32 s
     // Runtime-geometry rows (any dimension without a compile-time instantiation): the register tile, not the row, bounds what a
@@ -539,16 +554,16 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // in 1.98 s instead of 2.66 s (profiles/probe_r04d_build_dim*.jsonl) although the update stream then only runs where a
     // descent wave has retired.
     bool a_regs256 = tab16 && !rt_geometry;
-    if (const char* e = getenv("IDIST_BUILD_A_REGS")) a_regs256 = tab16 && atoi(e) == 256;
+    if (const char* e = test_env("IDIST_BUILD_A_REGS")) a_regs256 = tab16 && atoi(e) == 256;
     // steps of at most two insertions per CU run four waves per insertion (IDIST_BUILD_QUAD=0: never)
-    const bool a_quad = !(getenv("IDIST_BUILD_QUAD") && getenv("IDIST_BUILD_QUAD")[0] == '0');
+    const bool a_quad = !(test_env("IDIST_BUILD_QUAD") && test_env("IDIST_BUILD_QUAD")[0] == '0');
     const uint32_t quad_B = (uint32_t)ix->n_cu * 2u;
     // Narrow steps (four waves per insertion: their time does not depend on their width — one descent ≈ 0.45 ms) hold g / 8
     // insertions until they stop being narrow, wide ones g / 32: the first 16k points of a build take ≈ 60 steps instead of
     // ≈ 180 (100k x 128: 0.156 -> 0.122 s, 20k x 128: 0.078 -> 0.043 s, C3 -2.6 %; recall@10 unchanged to the fourth digit at
     // 5k / 20k / 100k / 1M points, profiles/probe_r04_build_growth_*.jsonl).  IDIST_BUILD_GROWTH=<d> (A/B knob, 8..32): g / d.
     uint32_t growth_div = 8u;
-    if (const char* e = getenv("IDIST_BUILD_GROWTH")) growth_div = (uint32_t)std::min(32, std::max(8, atoi(e)));
+    if (const char* e = test_env("IDIST_BUILD_GROWTH")) growth_div = (uint32_t)std::min(32, std::max(8, atoi(e)));
     // what one CU's LDS holds of them (the sequential schedule runs nothing beside the descents)
     const uint32_t a_waves_max = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (uint32_t)((160u * 1024u) / smem)));
     a_waves = std::min(a_waves, a_waves_max);
@@ -565,7 +580,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // the extra overlap costs 2 %), so they keep one descent stream and one update stream.
     // IDIST_BUILD_STREAMS=off | narrow (default) | all.
     int stream_mode = 1;
-    if (const char* e = getenv("IDIST_BUILD_STREAMS")) stream_mode = e[0] == 'o' ? 0 : (e[0] == 'a' ? 2 : 1);
+    if (const char* e = test_env("IDIST_BUILD_STREAMS")) stream_mode = e[0] == 'o' ? 0 : (e[0] == 'a' ? 2 : 1);
     bool two_a = !tie_spill && stream_mode != 0;
     bool own_a2 = stream_mode != 0;
     auto release = [&]() {
@@ -668,7 +683,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     a.tab16 = tab16 ? 1u : 0u;
     a.ubits = tab16 ? q16_universe_bits(n, tab_log2) : 0u;
     a.dl_shift = dl_shift;
-    a.use_dlog = getenv("IDIST_BUILD_NO_DLOG") ? 0u : 1u;
+    a.use_dlog = test_env("IDIST_BUILD_NO_DLOG") ? 0u : 1u;
     a.wbuf = d_wbuf;
     a.wcount = d_wcount;
     a.rt2 = rt2;
@@ -676,10 +691,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     a.tie_cap = tie_cap;
     a.tie_spill = d_tie_spill;
     a.tie_spill_cap = tie_spill ? n : 0u;
-    if (const char* e = getenv("IDIST_BUILD_CHUNK")) a.chunk = (uint32_t)atoi(e);
+    if (const char* e = test_env("IDIST_BUILD_CHUNK")) a.chunk = (uint32_t)atoi(e);
     const size_t smemF = smem_bytes_update_fast(ix->L.stride);
     [[maybe_unused]] const bool classic = knobs.classic;   // (test build: IDIST_VARIANT_BUILD)
-    const bool no_fast = getenv("IDIST_BUILD_NO_FAST") != nullptr;   // test knob: route every update through B2
+    const bool no_fast = test_env("IDIST_BUILD_NO_FAST") != nullptr;   // test knob: route every update through B2
     a.stats = d_stats;
 
     uint32_t cum[IDIST_MAX_LAYERS + 1];
@@ -837,7 +852,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     }
     if (pipe) {
         if (n_batches) BCHK(hipStreamWaitEvent(s1, evS[n_batches & 1u], 0));
-        if (getenv("IDIST_BUILD_CHECK")) {
+        if (test_env("IDIST_BUILD_CHECK")) {
             // self-check: carry the last step over as well; now the two copies must agree on every row, or some
             // step's carry-over missed a row
             const int par = (int)(n_batches & 1u);
@@ -916,7 +931,7 @@ idist_status build_common(const void* points, bool on_device, uint32_t n, uint32
     idist_progress* prog = g_watch;
     g_watch = nullptr;
     idist_config c = *cfg;
-    const bool spill_first = getenv("IDIST_TIE_SPILL") && getenv("IDIST_TIE_SPILL")[0] == '1';   // test knob, see Knobs
+    const bool spill_first = test_env("IDIST_TIE_SPILL") && test_env("IDIST_TIE_SPILL")[0] == '1';   // test knob, see Knobs
     bool tie_spill = false;
     for (;;) {
         idist_index* ix = nullptr;
@@ -2016,7 +2031,7 @@ static idist_status bruteforce_mfma(const idist_index* idx, const float* queries
     *fell_back = 0;
     const uint32_t n = idx->n, stride = idx->L.stride;
     uint32_t S = 32768;
-    if (const char* e = getenv("IDIST_BF_SAMPLE")) S = (uint32_t)atoi(e);
+    if (const char* e = test_env("IDIST_BF_SAMPLE")) S = (uint32_t)atoi(e);
     S = std::min(std::max(S, k), n);
     const uint32_t S_pad = (S + kTN - 1) / kTN * kTN;
     const uint32_t QC = 8192;                                    // queries per pass (bounds the dense sample matrix)
@@ -2113,7 +2128,7 @@ idist_status idist_bruteforce(const idist_index* idx, const float* queries, uint
     if (!queries || !out_pid || !out_dist) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
     // the -2QP^T contraction only pays when the batch is wide enough to be a dense GEMM
     bool mfma = nq >= 256 && idx->n >= 16384;
-    if (const char* e = getenv("IDIST_BRUTEFORCE")) mfma = strcmp(e, "mfma") == 0 ? true : (strcmp(e, "scan") == 0 ? false : mfma);
+    if (const char* e = test_env("IDIST_BRUTEFORCE")) mfma = strcmp(e, "mfma") == 0 ? true : (strcmp(e, "scan") == 0 ? false : mfma);
     if (mfma && idx->n >= k && idx->n >= 128) {
         HIPCHK(hipSetDevice(idx->device));
         int fell_back = 0;

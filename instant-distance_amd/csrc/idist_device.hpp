@@ -1283,7 +1283,9 @@ constexpr uint32_t kSpecAbort = 0xFFFFFFFFu;            // spec_n: the row holds
 // stands between "the helpers were released" and "the leader posts again").  Every wave counts the A barriers it passed.
 struct QuadCtl {
     uint32_t cmd[2], na[2], spec_n, pad[3];
-    uint32_t spec_row[64];                               // leader -> helpers: the predicted candidate's adjacency row (slot order)
+    uint32_t spec_row[2][64];                            // leader -> helpers: the predicted candidate's adjacency row (slot order), kept
+                                                         // by the parity of its barrier like cmd / na: after a wrong guess and an own pass
+                                                         // of one round no barrier separates one speculation's row from the next one's
     uint32_t spec_new[64];                               // helpers -> leader: its new ids, compacted in slot order
     uint32_t spec_dist[64];                              // ... and their canonical distance bits
 };
@@ -1310,7 +1312,7 @@ __device__ __forceinline__ void quad_dist_pass(const IndexView& ix, const float*
 }
 // leader: hand the predicted candidate's row to the helpers (row_id: this lane's slot of it, kInvalid beyond its end)
 __device__ __forceinline__ void quad_post_spec(QuadLead& ql, uint32_t row_id) {
-    ql.ctl->spec_row[lane_id()] = row_id;
+    ql.ctl->spec_row[ql.seq & 1u][lane_id()] = row_id;
     ql.post(kQuadSpec);
 }
 // leader: wait for the speculation it asked for; number of new ids in ctl->spec_new / spec_dist, or kSpecAbort
@@ -1343,7 +1345,7 @@ __device__ __forceinline__ void quad_helper_loop(const IndexView& ix, const floa
 #ifdef IDIST_PROBE
             const unsigned long long hp0 = wall_clock64();
 #endif
-            const uint32_t id = ctl->spec_row[lane];
+            const uint32_t id = ctl->spec_row[seq & 1u][lane];
             const uint64_t inval = __ballot(id == kInvalid);
             const int nv = inval ? __builtin_ctzll(inval) : 64;
             bool fresh = false, other = false;                         // other: only the bitmap knows

@@ -85,19 +85,32 @@ def variants_lib():
     return _VARIANTS_LIB
 
 
+def use_test_build(monkeypatch):
+    """For the rest of this test the engine is the TEST build: libidist.so reads no IDIST_* knob but IDIST_COMBINE / IDIST_SYNC /
+    IDIST_KERNEL_EVENTS (the others are compiled out of the product), so a GPU test that steers kernels or schedules through the
+    environment runs libidist_variants.so — the same sources and struct layouts plus the knobs and the walks no policy selects.
+    Handles made by either library are valid in the other.  (The emulator build holds every knob and variant.)"""
+    if not _emulated():
+        from instant_distance_amd import _capi
+        _capi.lib()
+        monkeypatch.setattr(_capi, "_singleton", variants_lib())
+
+
 @contextlib.contextmanager
 def search_variant(env):
-    """Environment of one walk variant.  Variants that exist in the test build only (IDIST_WALK=classic) run through
-    libidist_variants.so on the GPU: the same sources and struct layouts as libidist.so plus those kernels, so handles made
-    by either library are valid in the other (an index imported before the block is searched inside it, an index built
-    inside it is exported after it).  The emulator build holds every variant."""
+    """Environment of one walk variant.  A non-empty environment selects kernels through test knobs, which exist in the test build
+    only: on the GPU the block runs through libidist_variants.so (see use_test_build: an index imported before the block is searched
+    inside it, an index built inside it is exported after it); the default variant ({}) runs the product library."""
     if isinstance(env, str):                     # a bare IDIST_LATENCY_NQ value
         env = {"IDIST_LATENCY_NQ": env}
+    from instant_distance_amd import _capi
     swapped = None
-    if env.get("IDIST_WALK") == "classic" and not _emulated():
-        from instant_distance_amd import _capi
-        swapped = _capi._singleton
-        _capi._singleton = variants_lib()
+    if env and not _emulated():
+        swapped = _capi.lib()                    # (loads the product library if nothing is loaded yet: there is always one to restore)
+        if swapped is not variants_lib():
+            _capi._singleton = variants_lib()
+        else:
+            swapped = None
     keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ", "IDIST_BUILD_A2",
             "IDIST_TAB_FORMAT", "IDIST_BUILD_NO_FAST", "IDIST_BUILD_QUAD", "IDIST_BUILD_A_REGS", "IDIST_W2_EF")
     old = {k: os.environ.get(k) for k in keys}
@@ -108,7 +121,6 @@ def search_variant(env):
         yield
     finally:
         if swapped is not None:
-            from instant_distance_amd import _capi
             _capi._singleton = swapped
         for k in keys:
             os.environ.pop(k, None)

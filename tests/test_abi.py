@@ -88,3 +88,22 @@ def test_header_is_plain_c99(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                            "-I", os.path.join(root, "include"), str(src)])
+
+
+def test_product_library_reads_three_environment_knobs_only():
+    """libidist.so: IDIST_COMBINE, IDIST_SYNC, IDIST_KERNEL_EVENTS.  Every other IDIST_* knob (which walk, which schedule, which
+    visited set ...) is compiled out of the product (test_env() in idist_capi.hip) and lives in libidist_variants.so, the test
+    build: no environment variable can change which kernels the product runs or which graph it builds."""
+    import re
+
+    from instant_distance_amd import _capi
+
+    def knob_names(path):
+        blob = open(path, "rb").read()
+        return {m.decode() for m in re.findall(rb"IDIST_[A-Z0-9_]+", blob)}
+
+    allowed = {"IDIST_COMBINE", "IDIST_SYNC", "IDIST_KERNEL_EVENTS"}
+    not_knobs = {"IDIST_M", "IDIST_M2", "IDIST_TIES_DROP"}               # constants of include/idist.h named in error messages
+    assert knob_names(_capi.LIB_PATH) - not_knobs == allowed
+    variants = os.path.join(os.path.dirname(_capi.LIB_PATH), "libidist_variants.so")
+    assert {"IDIST_WALK", "IDIST_BUILD_PIPELINE", "IDIST_BUILD_GROWTH", "IDIST_TAB_LOG2", "IDIST_W2_EF"} <= knob_names(variants)

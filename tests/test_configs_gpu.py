@@ -76,7 +76,7 @@ def test_bench_under_torchrun_one_rank_gpu():
 
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C2", "--n", "50000", "--nq", "2000",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C2", "--points", "50000", "--nq", "2000",
            "--steps", "3", "--warmup", "1", "--threads", "", "--cpu-sample", "512", "--cpu-build-sample", "0", "--no-traffic", "--check"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

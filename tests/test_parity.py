@@ -205,6 +205,7 @@ def test_c2_full_size_properties_gpu(engine_loader, oracle):
 def test_build_batched(eng, oracle, monkeypatch, pipeline):
     # both schedules of a concurrent build: pipelined (descents of step k+1 overlap the updates of step k) and not
     ida, kind = eng
+    pc.use_test_build(monkeypatch)                     # (schedule knobs exist in the test build only)
     monkeypatch.setenv("IDIST_BUILD_PIPELINE", pipeline)
     monkeypatch.setenv("IDIST_BUILD_CHECK", "1")      # pipelined: the two copies of the zero layer must agree at the end
     rec = pc.check_build_batched(ida, oracle, n=S(kind, 220, 30000), dim=S(kind, 4, 32), max_batch=S(kind, 4, 0),
@@ -218,6 +219,7 @@ def test_build_batched_is_schedule_independent(eng, oracle, monkeypatch):
     off), with every update forced through the from-scratch kernel, and with the latency / throughput descent
     give byte-identical graphs."""
     ida, kind = eng
+    pc.use_test_build(monkeypatch)                     # (schedule knobs exist in the test build only)
     rng = np.random.default_rng(4)
     pts = pc.gen_points(rng, S(kind, 150, 60000), S(kind, 6, 48), "lowrank" if kind == "gpu" else "uniform")
     b = ida.Builder().max_batch(S(kind, 16, 0))
@@ -231,8 +233,7 @@ def test_build_batched_is_schedule_independent(eng, oracle, monkeypatch):
         # the published log, how early the descents' visited set spills: none of it may show in the graph
         envs += [{"IDIST_BUILD_A2": "tile"}, {"IDIST_BUILD_NO_DLOG": "1"}, {"IDIST_TAB_LOG2": "7"}]
     for env in envs:
-        # (IDIST_WALK=classic exists in the test build only: search_variant routes it to libidist_variants.so on the GPU)
-        with pc.search_variant({k_: v for k_, v in env.items() if k_ == "IDIST_WALK"}), monkeypatch.context() as m:
+        with monkeypatch.context() as m:
             m.setenv("IDIST_BUILD_CHECK", "1")
             for k_, v in env.items():
                 m.setenv(k_, v)
@@ -364,6 +365,7 @@ def test_bruteforce_mfma_path_equals_scan(eng, oracle, monkeypatch):
     pts = rng.standard_normal((n, dim)).astype(np.float32)
     q = rng.standard_normal((nq, dim)).astype(np.float32)
     q[:3] = pts[[5, 17, n - 1]]
+    pc.use_test_build(monkeypatch)                     # (IDIST_BRUTEFORCE / IDIST_BF_SAMPLE exist in the test build only)
     h = ida.Hnsw.from_parts(pts, np.full((n, 64), pc.INVALID, np.uint32), [], ida.Builder())
     monkeypatch.setenv("IDIST_BRUTEFORCE", "scan")
     p1, d1 = h.bruteforce(q, k)
@@ -656,6 +658,7 @@ def test_strict_ties_spill_to_hbm(eng, oracle, monkeypatch):
     (distance, pid) order: with a ONE-entry region on integer-grid data nearly every tie takes that road, and search (every
     walk variant) and exact build must still be the oracle's, bit for bit."""
     ida, kind = eng
+    pc.use_test_build(monkeypatch)                     # (IDIST_TIE_SPILL exists in the test build only)
     monkeypatch.setenv("IDIST_TIE_SPILL", "1")
     rng = np.random.default_rng(23)
     n, ef = S(kind, 300, 8000), S(kind, 12, 60)

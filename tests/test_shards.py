@@ -132,6 +132,7 @@ def test_narrow_host_batches_zero_copy_equals_staged(eng, oracle, monkeypatch):
     reads the queries and writes the results itself, the work-queue head runs on from launch to launch); wider ones and
     IDIST_NO_ZERO_COPY=1 take the staged copies.  Same results either way, call after call on one context, and == oracle."""
     ida, kind = eng
+    pc.use_test_build(monkeypatch)                     # (IDIST_NO_ZERO_COPY exists in the test build only)
     rng = np.random.default_rng(5)
     n, dim = S(kind, 220, 6000), S(kind, 6, 48)
     pts = rng.random((n, dim), dtype=np.float32)
