@@ -295,8 +295,6 @@ struct idist_search_ctx {
     uint32_t* d_ctr = nullptr;
     size_t cap_q = 0, cap_out = 0, cap_nq = 0;
     bool tie_overflowed = false;
-    bool placed = false;           // the visited bitmaps' allocation was chosen by place_visited (again false once they grow)
-    bool placing = false;          // ... which is running right now (its own launches do not calibrate)
     uint32_t tie_cap = 0;          // tie capacity this context escalated to (0 = the index's)
     // strict ties, last resort: one bag of n keys per slot in HBM (the reference's candidate heap is unbounded, core/lib.rs:564)
     bool tie_spill = false;        // later launches attach the bags
@@ -404,6 +402,9 @@ uint32_t default_slots(uint32_t n_points, int n_cu) {
 
 // LDS one wave of the on-chip walk may use: one wave per SIMD, four per CU, out of 160 KiB
 constexpr size_t kOnChipLdsPerWave = 40 * 1024;
+// point rows of at most this many bytes are served out of the Infinity Cache (256 MiB) rather than HBM: latency, not bandwidth, bounds
+// the walks on them (launch_search and run_build choose their wave layouts by it)
+constexpr size_t kCacheResidentBytes = (size_t)128 << 20;
 
 thread_local uint32_t g_tie_cap_msg = kTieCap;
 uint32_t tie_capacity(const idist_config& cfg) { return g_tie_cap_msg = cfg.tie_capacity ? cfg.tie_capacity : (uint32_t)kTieCap; }
@@ -555,7 +556,11 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // CU: one 512-register wave per SIMD (2 x 4 x 8 = 64 KB each) builds 1M x 1024-d in 4.35 s instead of 9.6 s and 1M x 384-d
     // in 1.98 s instead of 2.66 s (profiles/probe_r04d_build_dim*.jsonl) although the update stream then only runs where a
     // descent wave has retired.
-    bool a_regs256 = tab16 && !rt_geometry;
+    // An index that sits in the Infinity Cache (100k x 128: 51 MB) is bound by the latency of an expansion, not by what the update
+    // stream leaves of the memory system: one fat wave per SIMD (more rows of an expansion in one round trip) builds C2 in 0.110 s
+    // instead of 0.121 s; five to eight thin waves per CU 0.117-0.122 s (profiles/probe_r05c_build_descent_waves_c2.jsonl).
+    const bool cache_resident = (size_t)n * ix->L.stride * 4 <= kCacheResidentBytes;
+    bool a_regs256 = tab16 && !rt_geometry && !cache_resident;
     if (const char* e = test_env("IDIST_BUILD_A_REGS")) a_regs256 = tab16 && atoi(e) == 256;
     // steps of at most two insertions per CU run four waves per insertion (IDIST_BUILD_QUAD=0: never)
     const bool a_quad = !(test_env("IDIST_BUILD_QUAD") && test_env("IDIST_BUILD_QUAD")[0] == '0');
@@ -730,7 +735,11 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             const uint64_t k = n_batches + 1;                              // step number, 1-based
             const int par = (int)(k & 1u);
             const bool alt = stream_mode == 2 || (stream_mode == 1 && B <= quad_B);   // this step on the extra streams
-            hipStream_t sA = pipe ? (two_a && alt && par ? s3 : s1) : stream, sS = pipe ? s2 : stream;
+            // a sequential step (B = 1: the top layer, the first 63 points) depends on the whole previous step anyway: all of its
+            // launches go to the update stream — same-stream boundaries (~2 us) instead of three cross-stream event hops (~27 us each
+            // in the trace of profiles/trace_chain_r05b_build_c2.json: 74 of the 179 us such a step took)
+            const bool seq1 = pipe && B == 1;
+            hipStream_t sA = pipe ? (seq1 ? s2 : (two_a && alt && par ? s3 : s1)) : stream, sS = pipe ? s2 : stream;
             IndexView viewA = view, viewS = view;
             BuildArgs aA = a;
             if (pipe) {
@@ -770,7 +779,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             // (carry-over of the previous step's rows: its touched list)
             const uint32_t* const prev_touched = own_a2 ? d_touched + (par ? 0 : n_touch) : a.touched;
             const uint32_t* const prev_cnt = own_a2 ? smallS + (par ? 0 : 8) : smallS;
-            hipStream_t sA2 = own_a2 && alt ? s4 : sS;
+            hipStream_t sA2 = own_a2 && alt && !seq1 ? s4 : sS;
             BuildArgs af = aS;
             af.efc = no_fast ? 0u : cfg.ef_construction;                  // efc = 0 makes the fast kernel defer everything
 #ifdef IDIST_VARIANTS
@@ -978,7 +987,6 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
     hipFree(ctx->d_visited);
     ctx->d_visited = fresh;
     ctx->slots = s;
-    ctx->placed = false;
     return IDIST_OK;
 }
 
@@ -999,93 +1007,21 @@ inline uint32_t on_chip_max_ef(uint32_t stride_floats) {
     const int ef = (int)stride_floats * 61 / 25 - 132;
     return (uint32_t)std::min(1536, std::max(160, ef));
 }
-constexpr size_t kCacheResidentBytes = (size_t)128 << 20;
 constexpr uint32_t kLongWalkEf = 512u;   // ef_search from which wide on-chip batches run two thinner waves per SIMD (see launch_search)
 
+// Long walks and where the visited bitmaps land (round 5, measured, nothing kept): ef_search 800 at 1M points test-and-sets the HBM
+// bitmaps ~36k times per query, and five fresh contexts on ONE index in one process answer the same 10k queries in 72.5 / 72.9 / 79.1 /
+// 82.3 / 82.4 ms while fresh replicas of the index behind fresh contexts change nothing — the spread between fresh processes is the
+// CONTEXT's allocation, not the index's (profiles/probe_r05b_placement_ef800_contexts_vs_replicas_c3.jsonl).  The pattern alone
+// (scripts/micro/bitmap_placement.hip) is placement-independent; beside random row gathers it shows the same discrete levels (3 %): the
+// 192 MB of hot bitmap lines and the row gathers compete for the 256-MiB Infinity Cache, and how well the bitmaps stay in it depends on
+// physical placement.  Choosing among four candidate allocations by timing the real kernel (round 1's cure for the byte array) found a
+// fast one on one box (four of five processes at 74-76 ms) and none on the next (five of five at 82.7 ms) for ~0.2 s per context: not
+// kept.  Gathering the rows with the non-temporal hint (leaving the cache to the bitmaps) costs 11-15 % at every ef_search and 30 % of
+// the build (`make nt`, profiles/probe_r05e_rows_nontemporal_ab_c3.jsonl): the row gathers live on Infinity-Cache hits too.
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
                            uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream,
-                           uint32_t* status_host = nullptr, uint32_t* grid_out = nullptr, uint32_t* done_host = nullptr, uint32_t done_seq = 0);
-
-// Long walks test-and-set the HBM bitmaps behind the on-chip set tens of thousands of times per query (ef_search 800 at 1M points:
-// ~43k visits, 7k of them on chip), one dependent round trip each, and how fast those are depends on WHICH allocation the bitmaps
-// got: five fresh contexts on one index in one process answer the same 10k queries in 72.5 / 72.9 / 79.1 / 82.3 / 82.4 ms, fresh
-// replicas of the index behind one context change nothing (profiles/probe_r05b_placement_ef800_contexts_vs_replicas_c3.jsonl) — the
-// "11 % between fresh processes" of round 4.  What the driver's allocator hands out cannot be asked for, so it is measured: before a
-// context's first wide long-walk launch up to four candidate allocations answer a throw-away batch (the first rows of the index as
-// queries) through the very kernel that is about to run, the fastest stays, the others are freed.  Once per context (and again
-// should its bitmaps grow); ~0.2 s at 1M points; results cannot depend on it (the bitmaps are all-zero between launches).
-idist_status place_visited(const idist_index* ix, idist_search_ctx* ctx, uint32_t cal_nq, hipStream_t stream) {
-    ctx->placed = true;                                        // whatever happens below: once
-    int tries = 4;
-    if (const char* e = test_env("IDIST_PLACE_TRIES")) tries = std::min(8, std::max(1, atoi(e)));
-    const size_t vb = std::max<size_t>((size_t)ctx->slots * ctx->vis.slot_words * 4, 256);
-    size_t freeb = 0, totalb = 0;
-    if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) return IDIST_OK;
-    tries = (int)std::min<size_t>((size_t)tries, freeb / 4 / vb + 1);      // the candidates together take at most a quarter of what is free
-    if (tries < 2) return IDIST_OK;
-    const uint32_t ef = ix->cfg.ef_search;
-    float* d_q = nullptr;
-    float* d_dist = nullptr;
-    uint32_t *d_pid = nullptr, *d_cnt = nullptr;
-    uint32_t* cand[8] = {ctx->d_visited};
-    int have = 1;
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    auto release = [&](int keep) {
-        hipFree(d_q); hipFree(d_dist); hipFree(d_pid); hipFree(d_cnt);
-        for (int t = 0; t < have; t++)
-            if (t != keep) hipFree(cand[t]);
-        if (t0) hipEventDestroy(t0);
-        if (t1) hipEventDestroy(t1);
-        (void)hipGetLastError();
-    };
-    uint32_t status_before = 0;
-    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(&status_before, ctx->d_next + 1, 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMalloc((void**)&d_q, (size_t)cal_nq * ix->dim * 4) != hipSuccess || hipMalloc((void**)&d_pid, (size_t)cal_nq * ef * 4) != hipSuccess ||
-        hipMalloc((void**)&d_dist, (size_t)cal_nq * ef * 4) != hipSuccess || hipMalloc((void**)&d_cnt, (size_t)cal_nq * 4) != hipSuccess ||
-        hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess ||
-        hipMemcpy2D(d_q, (size_t)ix->dim * 4, ix->d_points, (size_t)ix->L.stride * 4, (size_t)ix->dim * 4, cal_nq, hipMemcpyDeviceToDevice) != hipSuccess) {
-        release(0);
-        return IDIST_OK;                                       // no calibration: the first allocation stays
-    }
-    for (; have < tries; have++) {
-        cand[have] = nullptr;
-        if (hipMalloc((void**)&cand[have], vb) != hipSuccess || hipMemset(cand[have], 0, vb) != hipSuccess) {
-            hipFree(cand[have]);
-            (void)hipGetLastError();
-            break;
-        }
-    }
-    const bool events = ctx->knobs.events;
-    ctx->knobs.events = false;                                 // the throw-away launches are not the caller's: no kernel-time records
-    ctx->placing = true;
-    int pick = 0;
-    float best = 1e30f;
-    idist_status st = IDIST_OK;
-    for (int t = 0; t < have && st == IDIST_OK; t++) {
-        ctx->d_visited = cand[t];
-        float ms = 1e30f;
-        for (int rep = 0; rep < 2 && st == IDIST_OK; rep++) {   // (the first launch on a candidate warms its pages)
-            hipEventRecord(t0, stream);
-            st = launch_search(ix, ctx, d_q, cal_nq, d_pid, d_dist, d_cnt, nullptr, stream);
-            hipEventRecord(t1, stream);
-            if (hipEventSynchronize(t1) != hipSuccess) st = fail(IDIST_ERR_HIP, "place_visited: %s", hipGetErrorString(hipGetLastError()));
-            float m = 0.f;
-            if (st == IDIST_OK && rep > 0 && hipEventElapsedTime(&m, t0, t1) == hipSuccess) ms = m;
-        }
-        if (ms < best) { best = ms; pick = t; }
-    }
-    ctx->placing = false;
-    ctx->knobs.events = events;
-    ctx->d_visited = cand[pick];
-    // the device status word is the caller's: whatever the throw-away queries tripped (ties among stored points) is not
-    hipMemcpy(ctx->d_next + 1, &status_before, 4, hipMemcpyHostToDevice);
-    release(pick);
-    return st;
-}
-
-idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
-                           uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream,
-                           uint32_t* status_host, uint32_t* grid_out, uint32_t* done_host, uint32_t done_seq) {
+                           uint32_t* status_host = nullptr, uint32_t* grid_out = nullptr, uint32_t* done_host = nullptr, uint32_t done_seq = 0) {
     const uint32_t ef = ix->cfg.ef_search;
     CHK(variants_check(ctx->knobs.classic));
     SearchArgs a{};
@@ -1150,14 +1086,6 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
         a.tie_spill_cap = ix->n;
     }
     CHK(ensure_slots(ctx, std::min(nq, resident), stream));
-    // wide batches of walks that outgrow the on-chip set (or have none) on an index beyond the caches: choose the bitmaps' allocation
-    {
-        const bool force = test_env("IDIST_PLACE") && test_env("IDIST_PLACE")[0] == 'f';
-        const bool overflows = !on_chip || (!quad && 53u * ef + 600u > (q16 ? (2u << tab_log2) : (7u << tab_log2) / 8u));
-        if (!ctx->placed && !ctx->placing && !ctx->tie_spill && ix->n >= 1u &&
-            (force || (overflows && !cache_resident && nq >= 2048u && ix->n >= 65536u && ef >= kLongWalkEf)))
-            CHK(place_visited(ix, ctx, std::min(std::min(nq, 2048u), ix->n), stream));
-    }
     ctx->last_ef = ef;
     a.out_pid = d_pid;
     a.out_dist = d_dist;

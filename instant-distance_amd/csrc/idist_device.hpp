@@ -71,7 +71,17 @@ __host__ __device__ inline uint32_t blocked_pos(uint32_t e, uint32_t nb) {
     return e;
 }
 
+// one 16-B piece of a gathered point row.  -DIDIST_ROW_NT (measurement build `make nt`): with the non-temporal hint — rows are read
+// once per walk, the visited bitmaps of long walks are re-read dozens of times, and both compete for the Infinity Cache
+#ifdef IDIST_ROW_NT
+typedef float idist_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg_row4(const float* p) {
+    const idist_v4f v = __builtin_nontemporal_load(reinterpret_cast<const idist_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#else
 __device__ __forceinline__ float4 ldg_row4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#endif
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 // Wave-level sync: the lanes of ONE wavefront hand data to each other through LDS.  A wave's LDS instructions execute
@@ -537,8 +547,14 @@ constexpr int rounds_in_flight() {
 // register tile of the runtime geometry (dist_rounds_inflight_rt) by the kernel's register budget: one fat wave per SIMD
 // (512 registers) keeps 2 x 4 rounds x 8 blocks = 256 data registers = 64 KB on the wire; two waves per SIMD (256
 // registers: the build's descents) 2 x 3 x 4 = 96; the many-small-waves bitmap walks (16 per CU: 128 registers each) 2 x 1 x 4 = 32
-template <int WALK> constexpr int rt_rounds() { return walk_waves(WALK) == 1 ? 4 : (walk_waves(WALK) == 2 ? 3 : 1); }
-template <int WALK> constexpr int rt_blocks() { return walk_waves(WALK) == 1 ? 8 : 4; }
+#ifndef IDIST_RT2_ROUNDS          // (measurement builds override the two-waves-per-SIMD tile: -DIDIST_RT2_ROUNDS=4 -DIDIST_RT2_BLOCKS=4 ...)
+#define IDIST_RT2_ROUNDS 3
+#endif
+#ifndef IDIST_RT2_BLOCKS
+#define IDIST_RT2_BLOCKS 4
+#endif
+template <int WALK> constexpr int rt_rounds() { return walk_waves(WALK) == 1 ? 4 : (walk_waves(WALK) == 2 ? IDIST_RT2_ROUNDS : 1); }
+template <int WALK> constexpr int rt_blocks() { return walk_waves(WALK) == 1 ? 8 : (walk_waves(WALK) == 2 ? IDIST_RT2_BLOCKS : 4); }
 template <int NB, int RS, int TAIL, int WALK, class Mid = NoMid>
 __device__ __forceinline__ void dist_rounds_walk(const IndexView& ix, const float* q, const uint32_t* act_pid,
                                                  uint32_t* act_dist, int na, Mid mid = Mid(), uint32_t thr_bits = 0xFFFFFFFFu) {

@@ -16,6 +16,10 @@ import bench  # noqa: E402
 import instant_distance_amd as ida  # noqa: E402
 from instant_distance_amd import _capi  # noqa: E402
 
+# the knobs this script steers with exist in the test build only (libidist_variants.so); PB_LIB names another library
+torch.cuda.init()
+_capi._singleton = _capi.Lib(os.path.join(ROOT, "instant-distance_amd", "csrc", os.environ.get("PB_LIB", "libidist_variants.so")))
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "ab"
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "probe_ab.jsonl")
 if len(sys.argv) > 3:

@@ -14,6 +14,11 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 import instant_distance_amd as ida  # noqa: E402
+from instant_distance_amd import _capi  # noqa: E402
+
+if os.environ.get("PB_LIB"):          # an alternative build of the library (A/B in one box session)
+    torch.cuda.init()
+    _capi._singleton = _capi.Lib(os.path.join(ROOT, "instant-distance_amd", "csrc", os.environ["PB_LIB"]))
 
 fo = open(sys.argv[1], "a")
 dev = torch.device("cuda", 0)
@@ -38,7 +43,7 @@ for ef in [int(x) for x in os.environ.get("PB_EFS", "400,800").split(",")]:
     kt = r.search.kernel_times_ms(3)
     ctr = outs[3].cpu().numpy().astype(np.int64)
     nbytes = int((ctr[:, 0] * 4 * dim + ctr[:, 1] * 256 + ctr[:, 2] * 128 + 8 * ef).sum())
-    row = dict(probe="ef_once", commit=bench.source_stamp(), pid=os.getpid(), n=n, dim=dim, ef=ef, kernel_ms=[round(float(x), 3) for x in kt],
+    row = dict(probe="ef_once", commit=bench.source_stamp(), lib=os.environ.get("PB_LIB", "libidist.so"), build_s=round(h.build_stats().seconds, 4), pid=os.getpid(), n=n, dim=dim, ef=ef, kernel_ms=[round(float(x), 3) for x in kt],
                frac_of_8TBps=round(nbytes / (float(kt.min()) * 1e-3) / 8e12, 4), first_call_wall_ms=round(first_wall * 1e3, 1),
                answers_checksum=int(outs[0].to(torch.int64).sum().item()))
     print(json.dumps(row), flush=True)

@@ -13,6 +13,11 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 import instant_distance_amd as ida  # noqa: E402
+from instant_distance_amd import _capi  # noqa: E402
+
+# the knobs this script steers with exist in the test build only (libidist_variants.so); PB_LIB names another library
+torch.cuda.init()
+_capi._singleton = _capi.Lib(os.path.join(ROOT, "instant-distance_amd", "csrc", os.environ.get("PB_LIB", "libidist_variants.so")))
 
 dev = torch.device("cuda", 0)
 n, dim = 1_000_000, 300

@@ -200,43 +200,3 @@ def test_scalar_calls_from_many_threads_gpu(engine_loader, oracle, monkeypatch, 
     assert not any(t.is_alive() for t in ts), "a scalar call never returned"
     assert not errs, errs[:3]
 
-
-def test_bitmap_placement_calibration_changes_nothing_but_the_allocation(eng, oracle, monkeypatch):
-    """Before a context's first wide long-walk launch the library answers a throw-away batch on up to four candidate allocations
-    of the visited bitmaps and keeps the fastest (place_visited, idist_capi.hip).  Forced here at toy size (IDIST_PLACE=force, test
-    build): the caller's answers, work counters, kernel-time records and device status must be what they are without it — also
-    on tie-heavy data, where the throw-away queries (stored points) trip the tie-overflow flag the caller's queries do not."""
-    ida, kind = eng
-    pc.use_test_build(monkeypatch)
-    rng = np.random.default_rng(31)
-    n, dim, nq = S(kind, 260, 30000), S(kind, 6, 64), S(kind, 20, 3000)
-    pts = rng.random((n, dim), dtype=np.float32)
-    q = rng.random((nq, dim), dtype=np.float32)
-    oix = oracle.Index.build(pts, oracle.default_config(ef_search=60))
-    want = oix.search(q)
-    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().ef_search(60))
-    for tries in ("4", "2"):
-        monkeypatch.setenv("IDIST_PLACE", "force")
-        monkeypatch.setenv("IDIST_PLACE_TRIES", tries)
-        s = ida.Search()
-        for _ in range(2):                                              # the second call finds the context placed
-            pc.check_search_result(h.search_batch(q, s, counters=True), want)
-        s.check_status()
-        assert len(s.kernel_times_ms(8)) == 2                           # two launches are the caller's; the calibration's are not
-        pc.check_search_result(h.search_batch(q[:3], s, counters=True), oix.search(q[:3]))
-    # integer grid, DROP policy with a tiny tie region: stored points as queries overflow it, the caller's off-grid queries do not
-    g = rng.integers(0, 3, size=(S(kind, 300, 4000), 3)).astype(np.float32)
-    gq = (rng.random((S(kind, 12, 200), 3)) * 2).astype(np.float32)
-    cfg = oracle.default_config(ef_search=20, ef_construction=20)
-    gix = oracle.Index.build(g, cfg)
-    hb = ida.Builder().ef_search(20).ef_construction(20).tie_policy(ida.TIES_DROP).tie_capacity(1)
-    hg = ida.Hnsw.from_parts(g, gix.zero, gix.layers, hb)
-    monkeypatch.delenv("IDIST_PLACE")
-    s0 = ida.Search()
-    base = hg.search_batch(gq, s0, counters=True)
-    flagged0 = s0.tie_overflowed()
-    monkeypatch.setenv("IDIST_PLACE", "force")
-    s1 = ida.Search()
-    got = hg.search_batch(gq, s1, counters=True)
-    assert np.array_equal(got.pid, base.pid) and np.array_equal(got.counters, base.counters) and np.array_equal(got.count, base.count)
-    assert s1.tie_overflowed() == flagged0
