@@ -560,8 +560,16 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // stream leaves of the memory system: one fat wave per SIMD (more rows of an expansion in one round trip) builds C2 in 0.110 s
     // instead of 0.121 s; five to eight thin waves per CU 0.117-0.122 s (profiles/probe_r05c_build_descent_waves_c2.jsonl).
     const bool cache_resident = (size_t)n * ix->L.stride * 4 <= kCacheResidentBytes;
-    bool a_regs256 = tab16 && !rt_geometry && !cache_resident;
+    // Runtime-geometry rows of at most 12 blocks (<= 384-d) fit the 256-register tile whole (<6 blocks, 3 rounds>, two groups in
+    // flight) and build faster on it than on one fat wave per SIMD — 1M x 100 / 200 / 384-d: 1.11 / 1.30 / 1.75 s against 1.38 /
+    // 1.55 / 1.96 s; longer rows keep the fat waves (512-d: 2.35 against 3.12 s, 500k x 1024-d: 2.26 against 4.19 s;
+    // profiles/probe_r05g_build_rt_tile36_by_dim.jsonl).
+    bool a_regs256 = tab16 && !cache_resident && (!rt_geometry || ix->L.nb <= 12u);
     if (const char* e = test_env("IDIST_BUILD_A_REGS")) a_regs256 = tab16 && atoi(e) == 256;
+    // fat (512-register) descent waves take a SIMD's whole register file: where four of them sit on a CU, nothing of the update
+    // stream runs until one retires.  a_grid_cap (descent waves of a wide step; 0 = n_cu * a_waves) leaves SIMDs free on some CUs.
+    uint32_t a_grid_cap = 0;
+    if (const char* e = test_env("IDIST_BUILD_A_GRID")) a_grid_cap = (uint32_t)std::max(1, atoi(e));
     // steps of at most two insertions per CU run four waves per insertion (IDIST_BUILD_QUAD=0: never)
     const bool a_quad = !(test_env("IDIST_BUILD_QUAD") && test_env("IDIST_BUILD_QUAD")[0] == '0');
     const uint32_t quad_B = (uint32_t)ix->n_cu * 2u;
@@ -761,7 +769,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             } else {
                 BCHK(hipMemsetAsync(d_small, 0, 32, sA));                 // n_touched, queue heads, n_slow
             }
-            const uint32_t gridA = std::min(B, std::min<uint32_t>(slots, (uint32_t)ix->n_cu * (pipe ? a_waves : std::min(a_waves_max, a_regs256 ? 8u : 4u))));
+            uint32_t gridA = std::min(B, std::min<uint32_t>(slots, (uint32_t)ix->n_cu * (pipe ? a_waves : std::min(a_waves_max, a_regs256 ? 8u : 4u))));
+            if (a_grid_cap) gridA = std::min(gridA, a_grid_cap);
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
             const uint32_t gridS = std::min<uint32_t>(gridB, (uint32_t)ix->n_cu * 6);
             const uint32_t gridA2 = std::min<uint32_t>(B, (uint32_t)ix->n_cu * 4);

@@ -547,11 +547,14 @@ constexpr int rounds_in_flight() {
 // register tile of the runtime geometry (dist_rounds_inflight_rt) by the kernel's register budget: one fat wave per SIMD
 // (512 registers) keeps 2 x 4 rounds x 8 blocks = 256 data registers = 64 KB on the wire; two waves per SIMD (256
 // registers: the build's descents) 2 x 3 x 4 = 96; the many-small-waves bitmap walks (16 per CU: 128 registers each) 2 x 1 x 4 = 32
-#ifndef IDIST_RT2_ROUNDS          // (measurement builds override the two-waves-per-SIMD tile: -DIDIST_RT2_ROUNDS=4 -DIDIST_RT2_BLOCKS=4 ...)
+// (two waves per SIMD, 256 registers: <6 blocks, 3 rounds> = 2 x 3 x 6 float4 = 144 data registers, 36 KB on the wire per wave and a
+//  WHOLE row of up to 12 blocks (384-d) in flight; the <4, 3> tile of round 4 kept 8 of 12 blocks in flight and built 1M x 384-d in
+//  2.57-2.67 s where this one takes 1.75 s — profiles/probe_r05f_build_rt_tiles_dim384.jsonl.  Measurement builds override both.)
+#ifndef IDIST_RT2_ROUNDS
 #define IDIST_RT2_ROUNDS 3
 #endif
 #ifndef IDIST_RT2_BLOCKS
-#define IDIST_RT2_BLOCKS 4
+#define IDIST_RT2_BLOCKS 6
 #endif
 template <int WALK> constexpr int rt_rounds() { return walk_waves(WALK) == 1 ? 4 : (walk_waves(WALK) == 2 ? IDIST_RT2_ROUNDS : 1); }
 template <int WALK> constexpr int rt_blocks() { return walk_waves(WALK) == 1 ? 8 : (walk_waves(WALK) == 2 ? IDIST_RT2_BLOCKS : 4); }

@@ -38,7 +38,7 @@ pub(crate) struct IdistConfig {
     keep_pruned: i32,
     metric: i32,
     max_batch: u32,    // 0 = concurrent inserts (the rayon schedule of lib.rs:316-318), 1 = the sequential loop
-    tie_policy: i32,   // 0 = strict (IDIST_ERR_TIE_OVERFLOW), 1 = drop: see include/idist.h
+    tie_policy: i32,   // 0 = strict (the reference's results whatever the ties: the tie region grows, then spills to HBM), 1 = drop: see include/idist.h
     tie_capacity: u32, // 0 = 64
 }
 #[repr(C)] pub(crate) struct IdistIndex { _p: [u8; 0] }

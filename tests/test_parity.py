@@ -46,7 +46,8 @@ def test_search_parity_ef_sweep(eng, oracle, ef):
 
 
 def test_search_parity_ef_beyond_merge_width(eng, oracle):
-    # W longer than the 512 entries the one-pass merge of `push` covers: the sequential insertion path
+    # W longer than the one-pass merge of `push` covers (1024 entries in the fat waves, 512 elsewhere): on the GPU ef 1500 takes the
+    # sequential insertion path in every variant, under the emulator ef 600 does where the merge is 512 wide
     ida, kind = eng
     pc.check_search_parity(ida, oracle, n=S(kind, 640, 30000), dim=S(kind, 4, 64), ef_search=S(kind, 600, 1500),
                            nq=S(kind, 3, 64), seed=41)
