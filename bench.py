@@ -580,7 +580,7 @@ def rank0_report(job, args, cfgd, ida, r, outs, hnsw, d_pts, build, m):
     # cannot run inside the timed process); the newest committed result for the same workload is quoted beside it
     quoted, quoted_src, mall = None, None, None
     import glob
-    for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):   # newest round first
+    for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "traffic_r*.json"), recursive=True), key=os.path.basename, reverse=True):   # newest round first
         try:
             tj = json.load(open(tp))
             if tj.get("config", "C3") != args.config:

@@ -274,7 +274,7 @@ struct idist_search_ctx {
     uint32_t done_seq = 0;         // completion word of the last narrow host-pointer launch (h_io + kIoStatusSlots * 4)
     double call_ns_ema = 0.0;      // how long such a call has taken lately: the host sleeps through the first half of it
     uint64_t n_flag_calls = 0;
-    static constexpr size_t kIoMinBytes = 64 * 1024, kIoMaxBytes = 256 * 1024, kIoStatusSlots = 256, kIoHeadBytes = kIoStatusSlots * 4 + 64;   // ~100 queries: beyond that the staged copies are as fast (profiles/probe_r02_quad_single_query_phases.jsonl)
+    static constexpr size_t kIoMinBytes = 64 * 1024, kIoMaxBytes = 256 * 1024, kIoStatusSlots = 256, kIoHeadBytes = kIoStatusSlots * 4 + 64;   // ~100 queries: beyond that the staged copies are as fast (profiles/r02/probe_r02_quad_single_query_phases.jsonl)
     hipStream_t stream = nullptr;
     hipEvent_t ev0[IDIST_EVENT_RING] = {nullptr}, ev1[IDIST_EVENT_RING] = {nullptr};
     uint64_t n_launch = 0;
@@ -554,7 +554,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // Runtime-geometry rows (any dimension without a compile-time instantiation): the register tile, not the row, bounds what a
     // wave keeps on the wire, and the 256-register tile (2 x 3 rounds x 4 blocks = 24 KB) is too little at four waves per
     // CU: one 512-register wave per SIMD (2 x 4 x 8 = 64 KB each) builds 1M x 1024-d in 4.35 s instead of 9.6 s and 1M x 384-d
-    // in 1.98 s instead of 2.66 s (profiles/probe_r04d_build_dim*.jsonl) although the update stream then only runs where a
+    // in 1.98 s instead of 2.66 s (profiles/r04/probe_r04d_build_dim*.jsonl) although the update stream then only runs where a
     // descent wave has retired.
     // An index that sits in the Infinity Cache (100k x 128: 51 MB) is bound by the latency of an expansion, not by what the update
     // stream leaves of the memory system: one fat wave per SIMD (more rows of an expansion in one round trip) builds C2 in 0.110 s
@@ -566,17 +566,18 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // profiles/probe_r05g_build_rt_tile36_by_dim.jsonl).
     bool a_regs256 = tab16 && !cache_resident && (!rt_geometry || ix->L.nb <= 12u);
     if (const char* e = test_env("IDIST_BUILD_A_REGS")) a_regs256 = tab16 && atoi(e) == 256;
-    // fat (512-register) descent waves take a SIMD's whole register file: where four of them sit on a CU, nothing of the update
-    // stream runs until one retires.  a_grid_cap (descent waves of a wide step; 0 = n_cu * a_waves) leaves SIMDs free on some CUs.
-    uint32_t a_grid_cap = 0;
-    if (const char* e = test_env("IDIST_BUILD_A_GRID")) a_grid_cap = (uint32_t)std::max(1, atoi(e));
+    // (Fat descent waves take a SIMD's whole register file: where four of them sit on a CU, nothing of the update stream runs until
+    //  one retires — at 1024-d the selection's launches stretch to the descents' 13 ms and a step's period is 16.5 ms for 12.9 ms of
+    //  descents, profiles/trace_chain_r05i_build_500k_dim1024.json.  Measured and not kept: fewer descent waves per step, so that some
+    //  SIMDs stay free — 960 / 896 / 768 waves build 500k x 1024-d in 2.25 / 2.31 / 2.51 s against 2.20 s, probe_r05j; the update
+    //  streams at the highest priority — no difference at 1024 / 512 / 768 / 300-d, probe_r05k.)
     // steps of at most two insertions per CU run four waves per insertion (IDIST_BUILD_QUAD=0: never)
     const bool a_quad = !(test_env("IDIST_BUILD_QUAD") && test_env("IDIST_BUILD_QUAD")[0] == '0');
     const uint32_t quad_B = (uint32_t)ix->n_cu * 2u;
     // Narrow steps (four waves per insertion: their time does not depend on their width — one descent ≈ 0.45 ms) hold g / 8
     // insertions until they stop being narrow, wide ones g / 32: the first 16k points of a build take ≈ 60 steps instead of
     // ≈ 180 (100k x 128: 0.156 -> 0.122 s, 20k x 128: 0.078 -> 0.043 s, C3 -2.6 %; recall@10 unchanged to the fourth digit at
-    // 5k / 20k / 100k / 1M points, profiles/probe_r04_build_growth_*.jsonl).  IDIST_BUILD_GROWTH=<d> (A/B knob, 8..32): g / d.
+    // 5k / 20k / 100k / 1M points, profiles/r04/probe_r04_build_growth_*.jsonl).  IDIST_BUILD_GROWTH=<d> (A/B knob, 8..32): g / d.
     uint32_t growth_div = 8u;
     if (const char* e = test_env("IDIST_BUILD_GROWTH")) growth_div = (uint32_t)std::min(32, std::max(8, atoi(e)));
     // what one CU's LDS holds of them (the sequential schedule runs nothing beside the descents)
@@ -591,7 +592,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // get streams of their own: the descents of odd steps (s3) run beside those of even steps (s1), and the new points'
     // selection (s4: matrix cores and LDS) beside the previous step's neighbour updates (s2: dependent gathers).  Everything
     // a launch owns is kept per parity for that — visited bitmaps, work-queue heads, step-A outputs, the inboxes the selection
-    // hands to the updates.  Wide steps saturate the memory system whatever the layout (profiles/probe_r04_build_schedule:
+    // hands to the updates.  Wide steps saturate the memory system whatever the layout (profiles/r04/probe_r04_build_schedule:
     // the extra overlap costs 2 %), so they keep one descent stream and one update stream.
     // IDIST_BUILD_STREAMS=off | narrow (default) | all.
     int stream_mode = 1;
@@ -769,8 +770,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             } else {
                 BCHK(hipMemsetAsync(d_small, 0, 32, sA));                 // n_touched, queue heads, n_slow
             }
-            uint32_t gridA = std::min(B, std::min<uint32_t>(slots, (uint32_t)ix->n_cu * (pipe ? a_waves : std::min(a_waves_max, a_regs256 ? 8u : 4u))));
-            if (a_grid_cap) gridA = std::min(gridA, a_grid_cap);
+            const uint32_t gridA = std::min(B, std::min<uint32_t>(slots, (uint32_t)ix->n_cu * (pipe ? a_waves : std::min(a_waves_max, a_regs256 ? 8u : 4u))));
             const uint32_t gridB = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)B * IDIST_M2, g), (size_t)ix->n_cu * 16);
             const uint32_t gridS = std::min<uint32_t>(gridB, (uint32_t)ix->n_cu * 6);
             const uint32_t gridA2 = std::min<uint32_t>(B, (uint32_t)ix->n_cu * 4);
@@ -999,13 +999,13 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
     return IDIST_OK;
 }
 
-// Which walk serves a wide batch (profiles/probe_r02_ef_paths_onchip_vs_bitmap.jsonl, probe_r02_configs_c2_c4_c5.jsonl):
+// Which walk serves a wide batch (profiles/r02/probe_r02_ef_paths_onchip_vs_bitmap.jsonl, probe_r02_configs_c2_c4_c5.jsonl):
 //   * a search visits ~53 * ef_search + 600 nodes; the 8192-id on-chip set is frozen at 7168 and the rest of the walk
 //     test-and-sets the bitmap.  The fat on-chip waves still win while a row fetch outweighs that extra round trip:
 //     up to ef_search ~ 180 at 128-d, ~ 550 at 300-d (id set; ~ 600 with the quotient set), beyond 200 at 768-d;
 //   * an index that sits in the Infinity Cache (100k x 128: 51 MB) is served faster by 16 small waves per CU
 //     (4.2 vs 5.0 ms per 10k queries): the on-chip walk is for HBM-resident indexes.
-//   * round 4 (profiles/probe_r04f_ef_crossover_c3.jsonl, probe_r04i_ef_paths_wide_merge_c3.jsonl): with the quotient set the
+//   * round 4 (profiles/r04/probe_r04f_ef_crossover_c3.jsonl, probe_r04i_ef_paths_wide_merge_c3.jsonl): with the quotient set the
 //     crossover at 300-d moved from ~1.5 to ~2 x row floats, and once the fat waves merged a `nearest` of up to 1024 entries in
 //     one pass (w_push_merge<16>) the on-chip walk stayed ahead of the bitmap walk up to ef_search 1000 (0.651 / 0.637 / 0.625
 //     vs 0.628 / 0.620 / 0.611 of spec at 650 / 800 / 1000; beyond the merge's reach too: 0.628 vs 0.565 at ef 1000 in
@@ -1065,13 +1065,13 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     a.ubits = on_chip ? q16_universe_bits(ix->n, tab_log2) : 0u;
     // ... and the walk can outgrow the id form: a search visits ~53 * ef_search + 600 nodes (C3 / C4 / C5 data alike); while that
     // stays below the 7/8 * 2^tab_log2 ids the plain set takes, the plain set never spills and its cheaper probe wins by
-    // 1-2 % (ef_search = 100: 10.25 vs 10.42 ms per 10k queries at C3, profiles/probe_r03a_ef_paths_*)
+    // 1-2 % (ef_search = 100: 10.25 vs 10.42 ms per 10k queries at C3, profiles/r03/probe_r03a_ef_paths_*)
     const bool ids_suffice = 53u * ef + 600u <= (7u << tab_log2) / 8u;
     const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits) && (ctx->knobs.tab_q16 || ctx->knobs.tab_log2 || !ids_suffice);
     // Long walks (ef_search in the hundreds): an expansion costs a wave 9-10 us whatever it fetches, and it fetches fewer new rows
     // the longer the walk runs — more, thinner waves (two 256-register waves per SIMD, as many as the CU's LDS holds) keep more
     // expansions in flight than one fat wave per SIMD.
-    // Measured at 300-d (profiles/probe_r04k_ef_paths_two_waves_per_simd_c3.jsonl: ef 650 / 800 / 1000 at 0.704 / 0.690 / 0.651 of
+    // Measured at 300-d (profiles/r04/probe_r04k_ef_paths_two_waves_per_simd_c3.jsonl: ef 650 / 800 / 1000 at 0.704 / 0.690 / 0.651 of
     // spec against 0.653 / 0.639 / 0.628 for the fat waves, 0.787 against 0.795 at ef 400): from ef_search 512 on, for that row
     // geometry; other geometries keep the fat waves until they are measured (IDIST_W2_EF forces either way).
     const bool w2_geometry = ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1;

@@ -1271,7 +1271,7 @@ struct Counters {
 // spends ~0.3 us popping, ~1.0 on the adjacency row and the peek (a cold row on the 33 %), ~0.45 waiting for the helpers,
 // ~0.55 inserting, ~0.85 in its own passes, ~1.0 pushing; the helpers need ~0.4 us for the look-up and 1.6-1.9 for the rows.
 // The leader's serial chain bounds the walk, so what the protocol buys is small: 0.478 ms against 0.487 without it, same box
-// (profiles/probe_r04_quad_variants_same_box.jsonl).  Three richer protocols were built and measured on that box and dropped:
+// (profiles/r04/probe_r04_quad_variants_same_box.jsonl).  Three richer protocols were built and measured on that box and dropped:
 // knowing the next candidate before the merge (smallest new key against the first old un-expanded entry: every guess right,
 // new candidates' rows requested during the push) costs the leader more per expansion than the saved waits return (0.497);
 // adjacency two expansions ahead (0.485); helpers computing every slot of the row without looking at the set (0.494 in its
@@ -1540,7 +1540,11 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     constexpr bool OVL = walk_mode(LAT) != kWalkClassic && !walk_vis_lds(LAT);
     uint32_t pf_pid = kInvalid, pf_row = kInvalid;
     // four-wave walk with the visited set on chip: the helpers work one expansion ahead (QuadCtl)
-    constexpr bool kSpec = walk_quad(LAT) && walk_vis_lds(LAT) && PFA;
+    // the helpers work one expansion ahead — for the compile-time row geometries only: with the runtime-geometry tile the work-ahead
+    // COSTS a scalar call 9-26 % (1M x 200 / 384-d, 500k x 1024-d: 0.526 / 0.656 / 2.40 ms without it against 0.576 / 0.780 / 3.23 ms
+    // with it; 300-d: 0.478 with, 0.479 without — profiles/probe_r05l_single_query_rt_rows_ab.jsonl; round 4 measured it at 300-d and
+    // 768-d only)
+    constexpr bool kSpec = walk_quad(LAT) && walk_vis_lds(LAT) && PFA && NB >= 0;
     [[maybe_unused]] uint32_t sq_pid = kInvalid;          // the candidate whose row the helpers were given (wave-uniform)
     [[maybe_unused]] bool sq_off = false;                 // this layer met an id only the bitmap answers for: no more guesses
     QP_DECL
