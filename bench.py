@@ -726,6 +726,20 @@ def rank0_report(job, args, cfgd, ida, r, outs, hnsw, d_pts, build, m):
                                      "sample": f"first {nb_} of the {n} points, {cores} threads (prefix: optimistic for the CPU)",
                                      "seconds": round(tb_, 2)}
             build["gpu_over_cpu"] = round(build["points_per_s"] / build["cpu_baseline"]["value"], 1)
+        # the FULL-size CPU build takes minutes (1M x 300: 186 s on 16 threads), so it is not repeated in every run: the newest committed
+        # measurement of it for this shape is quoted beside the prefix (scripts/probe_build_quality.py: same points, same oracle, recall
+        # of both graphs through the engine)
+        for qp in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "probe_r*_build_quality_*.jsonl"), recursive=True), key=os.path.basename, reverse=True):
+            try:
+                rows = [json.loads(l) for l in open(qp) if l.startswith("{")]
+                full = [x for x in rows if x.get("builder", "").startswith("cpu oracle") and x.get("n") == n and x.get("dim") == dim]
+                if full:
+                    build["cpu_baseline_full_size_quoted"] = {"value": round(n / full[-1]["build_seconds"], 1), "unit": "points/s", "seconds": full[-1]["build_seconds"],
+                                                              "builder": full[-1]["builder"], "recall_at_10_ef100": full[-1].get("recall_at_10_ef100"),
+                                                              "source": os.path.relpath(qp, ROOT) + " (not this run)"}
+                    break
+            except Exception:  # noqa: BLE001
+                continue
         cpu = {"value": round(sample / tc, 1), "unit": "queries/s", "cores": cores, "kind": "port",
                "sample": f"first {sample} of the {nq} queries, same graph, ef_search={chosen}, {cores} threads = the "
                          f"container's CPU quota ({os.cpu_count()} logical CPUs visible) "

@@ -82,8 +82,8 @@ try:
             res["bench_traced_run"] = json.loads(line)
     for f in dbs("trace"):
         cur = sqlite3.connect(f).cursor()
-        # full-batch launches only (the 2048-query calibration launches of idist_search_ctx_new and the single-query
-        # probes use smaller grids / the latency walk)
+        # full-batch launches only (the ef sweep's other widths, the parity sample and the single-query probes use smaller grids /
+        # other walks)
         d = [r[0] for r in cur.execute("select end - start from kernels where name like '%search_kernel%' and grid_x = "
                                        "(select max(grid_x) from kernels where name like '%search_kernel%') order by start")]
         res["search_kernel_full_batch_launches"] = {"calls": len(d), "avg_us": round(sum(d) / max(len(d), 1) / 1e3, 1)}
@@ -140,8 +140,8 @@ if dest:
         for r in res.get("kernel_stats", []):
             f.write(f"| `{r['kernel'][:70]}` | {r['calls']} | {r['total_us']} | {r['avg_us']} | {r['pct']} |\n")
         if "search_kernel_full_batch_launches" in res:
-            f.write("\n`search_kernel` full-batch launches only (the table above also counts the 2048-query calibration launches of "
-                    "`idist_search_ctx_new`): " + json.dumps(res["search_kernel_full_batch_launches"]) + "\n")
+            f.write("\n`search_kernel` full-batch launches only (the table above also counts the launches of the ef sweep at ef 200, whose "
+                    "kernel runs longer, and the one-query probes): " + json.dumps(res["search_kernel_full_batch_launches"]) + "\n")
         f.write("\n## resources\n\n```\n" + json.dumps(res.get("kernel_resources", {}), indent=1) + "\n```\n")
         f.write("\n## PMC (per dispatch, KB as reported)\n\n```\nFETCH_SIZE " + json.dumps(res["pmc_FETCH_SIZE"], indent=1) +
                 "\nWRITE_SIZE " + json.dumps(res["pmc_WRITE_SIZE"], indent=1) + "\n```\n")
