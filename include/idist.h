@@ -23,38 +23,15 @@
  *   - there is no CPU fallback: without a gfx950 device every compute entry
  *     point fails with IDIST_ERR_NO_DEVICE.
  *
- * Environment knobs (measurement and test only; none changes a search result or an exact-mode build; sampled once
- * per context / per build; the full table with what each one is for is DESIGN.md's appendix):
- *   IDIST_WALK=classic      one distance round in flight, no adjacency prefetch (search and build descents): TEST BUILD ONLY
- *                           (libidist_variants.so; libidist.so answers IDIST_ERR_UNSUPPORTED)
- *   IDIST_VISITED=bitmap|onchip  force the bitmap + Bloom-filter walk / the on-chip visited set, whatever the policy says
- *   IDIST_TAB_LOG2=<5..13>  LDS of the on-chip visited set, 4 << n bytes (small sets exercise the overflow to the
- *                           bitmap; the build clamps it to >= 8); also forces the on-chip walk
- *   IDIST_TAB_FORMAT=ids|q16  the on-chip visited set always keeps full ids (4 per bucket, frozen at 7/8) / 16-bit quotients
- *                           (8 per bucket, single ids overflow) wherever they apply, whatever the policy says
+ * Environment: libidist.so reads exactly three variables, all host-side behaviour, sampled once per context —
  *   IDIST_COMBINE=0         every scalar host-pointer call makes its own launch (no riding along in another thread's launch)
  *   IDIST_SYNC=stream       narrow host-pointer calls wait with hipStreamSynchronize instead of for the kernel's completion word
- *   IDIST_TIE_SPILL=1       strict ties take the HBM bags at the first overflow instead of growing the LDS region first
- *   IDIST_BUILD_QUAD=0      narrow build steps (<= two insertions per CU) with one wave per insertion instead of four
- *   IDIST_BUILD_A_REGS=512|256  descents with one 512-register wave per SIMD / two 256-register waves (default: 256 for the
- *                           compile-time row geometries, 512 for runtime-geometry rows)
- *   IDIST_QUAD_NQ=<n>       batches of <= n queries run four waves per query (default two queries per CU; 0 = never)
- *   IDIST_W2_EF=<ef>        wide on-chip batches run two 256-register waves per SIMD from this ef_search on (default: 512 at 300-d)
- *   IDIST_LATENCY_NQ=<n>    bitmap walk only: batches of <= n queries run its latency variant (default 1024)
- *   IDIST_BLOOM=0           bitmap walk without the LDS Bloom filter
- *   IDIST_NO_ZERO_COPY=1    narrow host-pointer batches take the staged-copy path too
- *   IDIST_BRUTEFORCE=scan|mfma, IDIST_BF_SAMPLE=<n>   force a path of idist_bruteforce / its sample size
- *   IDIST_BUILD_PIPELINE=0  concurrent builds without the two-stream pipeline (a new point then sees all points up
- *                           to the previous step instead of the one before; graphs differ, quality does not)
- *   IDIST_BUILD_CHECK=1     self-check at the end of a pipelined build: both copies of the zero layer must agree
- *   IDIST_BUILD_A_WAVES=<1..8>  descent waves per CU in the pipelined schedule (default 4; 3 with the id set)
- *   IDIST_BUILD_STREAMS=off|narrow|all  extra streams of the pipelined build: never / in narrow steps (default) / in every step
- *   IDIST_BUILD_GROWTH=<8..32>  narrow steps of a concurrent build hold g / d insertions, g = points already in (default 8;
- *                           wide steps always g / 32); graphs differ, quality does not
- *   IDIST_BUILD_A2=tile     new points' select_heuristic with the LDS-tile kernel instead of the Gram matrix on MFMA
- *   IDIST_BUILD_NO_FAST=1   every neighbour update through the from-scratch kernel (no memoised re-selection)
- *   IDIST_BUILD_NO_DLOG=1   the memoised re-selection recomputes every distance instead of looking it up
- *   IDIST_BUILD_RT, IDIST_BUILD_RT2, IDIST_BUILD_CHUNK  build tile sizes / updates per work-queue dequeue
+ *   IDIST_KERNEL_EVENTS=0   no HIP events around the search kernels (idist_search_ctx_kernel_times then has nothing)
+ * — and nothing in the environment can change which kernels it runs or which graph it builds.  The knobs that select other
+ * implementations of the same decisions (IDIST_WALK, IDIST_VISITED, IDIST_TAB_*, IDIST_BUILD_*, ...) exist for the parity tests
+ * and A/B measurements and are compiled into the TEST build of the same sources only (libidist_variants.so, `make variants`;
+ * DESIGN.md's appendix lists them).  The library never edits the environment either: GPU_MAX_HW_QUEUES (one hardware queue per
+ * searching thread's stream) is the host's to set before its first HIP call.
  */
 #ifndef IDIST_H
 #define IDIST_H

@@ -1011,11 +1011,23 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
 //     vs 0.628 / 0.620 / 0.611 of spec at 650 / 800 / 1000; beyond the merge's reach too: 0.628 vs 0.565 at ef 1000 in
 //     probe_r04k).  Rows of >= 256 floats: on chip as far as LDS allows; shorter rows: the line through the 128-d (~180) and
 //     300-d (~600) crossovers.
-inline uint32_t on_chip_max_ef(uint32_t stride_floats) {
+//   * round 5 (profiles/probe_r05m_walk_policy_cache_resident.jsonl, probe_r05n_walk_policy_by_size_and_row.jsonl: on-chip walk vs
+//     bitmap walk at 9 more shapes): which walk wins near the Infinity Cache depends on the ROW LENGTH, not on residency alone.
+//     Rows of >= 256 floats: the on-chip walk wins by 5-8 % also where the index sits in the cache (100k x 300: 7.97 vs 8.51 ms,
+//     40k x 768: 17.2 vs 18.1 ms per 10k queries at ef 100; the same at ef 150-800).  Shorter rows: the bitmap walk wins well BEYOND
+//     the 128-MB mark — 300k x 128 (154 MB): 4.39 vs 4.69 ms at ef 100, 6.03 vs 7.50 at ef 150; 400k x 200-d (320 MB): 7.49 vs 8.76 and
+//     13.2 vs 17.8; 1M x 64-d (256 MB): 4.96 vs 6.84 — and loses from ~512 MB on (1M x 128: 6.73 vs 5.29 ms); and once such an index
+//     is far beyond the cache the on-chip walk stays ahead to higher ef_search (1M / 2M x 128 at ef 200: 10.6 / 10.9 against 11.8 /
+//     15.0 ms; 2M x 128 at ef 400: 23.0 against 27.5; 1M x 128 at ef 400: a tie).
+inline uint32_t on_chip_max_ef(uint32_t stride_floats, size_t index_bytes) {
     if (stride_floats >= 256u) return 1536u;       // (as far as W and the set fit a wave's LDS: tab_fit in launch_search)
     const int ef = (int)stride_floats * 61 / 25 - 132;
-    return (uint32_t)std::min(1536, std::max(160, ef));
+    return (uint32_t)std::min(1536, std::max(index_bytes >= ((size_t)512 << 20) ? 400 : 160, ef));
 }
+// short rows (< 256 floats) are served by the bitmap walk up to this many bytes of point rows (see above)
+constexpr size_t kShortRowBitmapBytes = (size_t)320 << 20;
+// ... and long rows by the on-chip walk from this size on (below it nothing was measured: the round-2 rule stands)
+constexpr size_t kLongRowOnChipBytes = (size_t)96 << 20;
 constexpr uint32_t kLongWalkEf = 512u;   // ef_search from which wide on-chip batches run two thinner waves per SIMD (see launch_search)
 
 // Long walks and where the visited bitmaps land (round 5, measured, nothing kept): ef_search 800 at 1M points test-and-sets the HBM
@@ -1055,9 +1067,11 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const uint32_t quad_per_cu = (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0) ? 1u : 2u;
     const uint32_t quad_nq = ctx->knobs.quad_nq == 0xFFFFFFFFu ? (uint32_t)ix->n_cu * quad_per_cu : ctx->knobs.quad_nq;
     const bool quad = tab_fit && !ctx->knobs.classic && nq <= quad_nq;
-    const bool cache_resident = (size_t)ix->n * ix->L.stride * 4 <= kCacheResidentBytes;
+    const size_t row_bytes = (size_t)ix->n * ix->L.stride * 4;
+    const bool long_rows = ix->L.stride >= 256u;
+    const bool cache_resident = long_rows ? row_bytes < kLongRowOnChipBytes : row_bytes <= kShortRowBitmapBytes;   // "served best by many small waves"
     const bool wide_on_chip = tab_fit && (ctx->knobs.vis_onchip || ctx->knobs.tab_log2 ||
-                                          (ef <= on_chip_max_ef(ix->L.stride) && !cache_resident));
+                                          (ef <= on_chip_max_ef(ix->L.stride, row_bytes) && !cache_resident));
     const bool on_chip = quad || wide_on_chip;
     const uint32_t tab_log2 = on_chip ? tab_fit : 0u;
     a.tab_log2 = tab_log2;
