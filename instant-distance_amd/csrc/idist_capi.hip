@@ -402,9 +402,6 @@ uint32_t default_slots(uint32_t n_points, int n_cu) {
 
 // LDS one wave of the on-chip walk may use: one wave per SIMD, four per CU, out of 160 KiB
 constexpr size_t kOnChipLdsPerWave = 40 * 1024;
-// point rows of at most this many bytes are served out of the Infinity Cache (256 MiB) rather than HBM: latency, not bandwidth, bounds
-// the walks on them (launch_search and run_build choose their wave layouts by it)
-constexpr size_t kCacheResidentBytes = (size_t)128 << 20;
 
 thread_local uint32_t g_tie_cap_msg = kTieCap;
 uint32_t tie_capacity(const idist_config& cfg) { return g_tie_cap_msg = cfg.tie_capacity ? cfg.tie_capacity : (uint32_t)kTieCap; }
@@ -556,15 +553,18 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // CU: one 512-register wave per SIMD (2 x 4 x 8 = 64 KB each) builds 1M x 1024-d in 4.35 s instead of 9.6 s and 1M x 384-d
     // in 1.98 s instead of 2.66 s (profiles/r04/probe_r04d_build_dim*.jsonl) although the update stream then only runs where a
     // descent wave has retired.
-    // An index that sits in the Infinity Cache (100k x 128: 51 MB) is bound by the latency of an expansion, not by what the update
-    // stream leaves of the memory system: one fat wave per SIMD (more rows of an expansion in one round trip) builds C2 in 0.110 s
-    // instead of 0.121 s; five to eight thin waves per CU 0.117-0.122 s (profiles/probe_r05c_build_descent_waves_c2.jsonl).
-    const bool cache_resident = (size_t)n * ix->L.stride * 4 <= kCacheResidentBytes;
-    // Runtime-geometry rows of at most 12 blocks (<= 384-d) fit the 256-register tile whole (<6 blocks, 3 rounds>, two groups in
-    // flight) and build faster on it than on one fat wave per SIMD — 1M x 100 / 200 / 384-d: 1.11 / 1.30 / 1.75 s against 1.38 /
-    // 1.55 / 1.96 s; longer rows keep the fat waves (512-d: 2.35 against 3.12 s, 500k x 1024-d: 2.26 against 4.19 s;
-    // profiles/probe_r05g_build_rt_tile36_by_dim.jsonl).
-    bool a_regs256 = tab16 && !cache_resident && (!rt_geometry || ix->L.nb <= 12u);
+    // Which register budget the descents take (same graphs either way; round 5):
+    //   * the 128-d instantiation (4 blocks): one fat wave per SIMD at EVERY size — C2 100k x 128: 0.110 against 0.121 s (five to
+    //     eight thin waves per CU: 0.117-0.122 s); 300k / 600k / 1M x 128: 0.245 / 0.449 / 0.713 s against 0.286 / 0.550 / 0.915 s
+    //     (profiles/probe_r05c_build_descent_waves_c2.jsonl, probe_r05p_build_regs_mid_size_short_rows.jsonl);
+    //   * 300-d and 768-d rows: two 256-register waves per SIMD, also where the index sits in the Infinity Cache (C3 1.26 against
+    //     1.29-1.32 s, C4 2.78-2.83 against 3.00-3.06 s; 40k x 768: 0.139 against 0.153 s; 60k-200k x 300: within 2 %,
+    //     probe_r05q_build_regs_cache_resident_long_rows.jsonl);
+    //   * runtime-geometry rows of at most 12 blocks (<= 384-d) fit the 256-register tile whole (<6 blocks, 3 rounds>, two groups in
+    //     flight) and build faster on it — 1M x 64 / 100 / 200 / 384-d: 0.91 / 1.11 / 1.30 / 1.75 s against 1.18 / 1.38 / 1.55 / 1.96 s;
+    //     longer rows keep the fat waves (512-d: 2.35 against 3.12 s, 500k x 1024-d: 2.26 against 4.19 s; probe_r05g_*, probe_r05p_*).
+    const bool rows128 = ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0;
+    bool a_regs256 = tab16 && !rows128 && (!rt_geometry || ix->L.nb <= 12u);
     if (const char* e = test_env("IDIST_BUILD_A_REGS")) a_regs256 = tab16 && atoi(e) == 256;
     // (Fat descent waves take a SIMD's whole register file: where four of them sit on a CU, nothing of the update stream runs until
     //  one retires — at 1024-d the selection's launches stretch to the descents' 13 ms and a step's period is 16.5 ms for 12.9 ms of
