@@ -1088,7 +1088,12 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // Measured at 300-d (profiles/r04/probe_r04k_ef_paths_two_waves_per_simd_c3.jsonl: ef 650 / 800 / 1000 at 0.704 / 0.690 / 0.651 of
     // spec against 0.653 / 0.639 / 0.628 for the fat waves, 0.787 against 0.795 at ef 400): from ef_search 512 on, for that row
     // geometry; other geometries keep the fat waves until they are measured (IDIST_W2_EF forces either way).
-    const bool w2_geometry = ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1;
+    // Round 5 (profiles/probe_r05r_long_walks_two_waves_other_geometries.jsonl): the same holds for runtime-geometry rows the
+    // 256-register tile keeps whole in flight (1M x 384-d: ef 600 / 800 at 79.1 / 105.1 ms against 88.5 / 114.6 ms, ef 400 within
+    // 2 %); not for 768-d (fat waves 1 % ahead at ef 400-800) and not for 128-d (thin waves 43 % slower at ef 400).
+    const bool rt_rows = !((ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
+                           (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0));
+    const bool w2_geometry = (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) || (rt_rows && ix->L.stride >= 256u && ix->L.nb <= 12u);
     const uint32_t w2_from = ctx->knobs.w2_ef != 0xFFFFFFFFu ? ctx->knobs.w2_ef : (w2_geometry ? kLongWalkEf : 0xFFFFFFFFu);
     const bool w2 = on_chip && q16 && !quad && !ctx->knobs.classic && ef >= w2_from;
     const uint32_t w2_per_cu = (uint32_t)std::min<size_t>(8, (size_t)160 * 1024 / smem_bytes(ix->L.stride, a.wcap, false, 1u << std::max(tab_log2, 5u), a.vis.dirty_words));

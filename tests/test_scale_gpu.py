@@ -88,23 +88,25 @@ def test_search_parity_runtime_geometry_at_size_gpu(engine_loader, oracle, n, di
 
 
 @pytest.mark.gpu
-def test_search_parity_long_walks_ef_600_to_1000_gpu(engine_loader, oracle):
+@pytest.mark.parametrize("n,dim,efs", [(200_000, 300, (600, 800, 1000, 1024, 513)), (120_000, 384, (600, 800))])
+def test_search_parity_long_walks_ef_600_to_1000_gpu(engine_loader, oracle, n, dim, efs):
     """ef_search in (512, 1024] in steady state, default policy (no environment knob): the sixteen-register-block merge of
     `Search::push` (core/lib.rs:704-720) and the two-256-register-waves-per-SIMD layout the policy picks from ef 512 at 300-d.
-    200,000 x 300 fastText-shape, GPU build, the oracle searches the exported graph (core/lib.rs:598-614); wide batch (one wave
-    per query) and a 64-query narrow batch (four waves per query): ids, order, counts, distance bits, work counters."""
+    200,000 x 300 fastText-shape (and 120,000 x 384: the runtime-geometry rows take the same layout from ef 512 on), GPU build, the
+    oracle searches the exported graph (core/lib.rs:598-614); wide batch (one wave per query) and a 64-query narrow batch (four
+    waves per query): ids, order, counts, distance bits, work counters."""
     import os
 
     for knob in ("IDIST_W2_EF", "IDIST_LATENCY_NQ", "IDIST_QUAD_NQ", "IDIST_VISITED", "IDIST_TAB_FORMAT", "IDIST_TAB_LOG2"):
         assert knob not in os.environ, f"{knob} is set: this case pins the DEFAULT policy"
     ida = engine_loader("gpu")
-    n, dim, nq = 200_000, 300, 2048
+    nq = 2048
     pts = fasttext_shape(n, dim, 21)
     q = fasttext_shape(nq, dim, 22)
     h = ida.Hnsw.from_ordered_points(pts, ida.Builder())
     zero, layers = h.into_parts()
     oix = oracle.Index.from_arrays(pts, zero, layers, oracle.default_config())
-    for ef in (600, 800, 1000, 1024, 513):
+    for ef in efs:
         h.set_ef_search(ef)
         oix.set_ef_search(ef)
         want = oix.search(q, threads=16)
