@@ -8,15 +8,24 @@ outputs resident in HBM.  N > 1 (launched by torch.distributed.run, one rank per
 builds the index, RCCL broadcasts it once over xGMI, every rank searches its own query
 shard, no collective inside the timed region.
 
+Structure: the measurement is a set of functions over a `Job` (the torch backend that carries the collectives, the
+device that holds the tensors, the libidist that answers) — phase_build, phase_replicate, phase_queries, phase_choose_ef,
+phase_timed, phase_replica_check, rank0_report, composed by run_bench().  main() makes the nccl / cuda Job;
+tests/test_distributed_gloo.py makes gloo / cpu Jobs around the emulator build of the product sources and runs the same
+functions at world sizes 2 and 3, so the N > 1 control flow has executed before an 8-GPU lease runs it.
+
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     HBM bound: algorithmic bytes per launch (B_q = n_dist*4*D + n_exp0*256 +
                n_expU*128 + 8*ef summed over the launch's queries, counted by the kernel itself
                and equal to the oracle's counters by bit-exactness) / average kernel duration
-               measured with HIP events on the launch stream.
+               measured with HIP events on the launch stream; `traffic` = fabric bytes per launch from two child passes
+               of this command under rocprofv3 --pmc, calibrated in the same pass (N = 1).
   cpu_baseline the CPU oracle (restated reference, NOT the Rust crate) searching the SAME graph
-               on the host cores for a bounded query sample.
+               on the host cores for a bounded query sample (rank 0 at N = 1 only).
   parity       (N = 1) the oracle's answers for a query sample at ef_search 100 / 200 / the timed one compared with
                the GPU's: ids, order, counts, distance bits, work counters.
+  replica_check (N > 1, and under torch.distributed.run at N = 1) every rank's answers for a common sample against rank 0's
+               (digest), rank 0's against the oracle.
   checks       (--check) size-independent properties of the results and of the built graph; tests/ assert on them.
 """
 import argparse

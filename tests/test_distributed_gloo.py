@@ -1,8 +1,11 @@
-"""N > 1 path on CPU: world_size 2, gloo.  Rank 0 builds, replicate_index() broadcasts the
-index once, every rank searches its contiguous query shard, results are gathered and must be
-identical to the oracle answering the whole batch.  Compute runs through the emulated kernels
-(tests/simt) because this container has no GPU; on the GPU box the same code path uses nccl
-(= RCCL) with zero-copy device views (instant-distance_amd/dist.py)."""
+"""N > 1 path on CPU (gloo; compute through the emulated kernels of tests/simt because this container has no GPU; on the GPU box
+the same code paths use nccl = RCCL with zero-copy device views, instant-distance_amd/dist.py):
+
+  * world size 2: rank 0 builds, replicate_index() broadcasts the index once, every rank searches its contiguous query shard,
+    results are gathered and must be identical to the oracle answering the whole batch;
+  * world sizes 2 and 3: bench.py's own N > 1 control flow — `bench.run_bench` over gloo / cpu Jobs — the weak-scaling line,
+    --config C5's split batch with uneven shards, and a deliberately corrupted replica that must stop every rank;
+  * -m gpu: backend nccl with one rank on the real device (scripts/nccl_selftest.py)."""
 import os
 import socket
 import sys
