@@ -1019,8 +1019,15 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
 //     13.2 vs 17.8; 1M x 64-d (256 MB): 4.96 vs 6.84 — and loses from ~512 MB on (1M x 128: 6.73 vs 5.29 ms); and once such an index
 //     is far beyond the cache the on-chip walk stays ahead to higher ef_search (1M / 2M x 128 at ef 200: 10.6 / 10.9 against 11.8 /
 //     15.0 ms; 2M x 128 at ef 400: 23.0 against 27.5; 1M x 128 at ef 400: a tie).
-inline uint32_t on_chip_max_ef(uint32_t stride_floats, size_t index_bytes) {
+//     Runtime-geometry rows shorter than 128 floats are different again: the fat waves' register tile (<8 blocks, 4 rounds>) keeps only
+//     4 x 8 rows x 256 B = 8 KB on the wire per wave at 64-d, and the bitmap walk wins at EVERY size — 4M x 64 (1 GB): 5.93 / 10.7 /
+//     20.1 ms against 7.13 / 14.9 / 31.0 ms at ef 100 / 200 / 400; at 100-d (3 blocks) it wins from ef ~150 on (3M x 100: 14.9 / 27.3
+//     against 16.3 / 34.0 ms at ef 200 / 400, a tie at ef 100); 200-d rows behave like the 128-d instantiation (2M x 200: on chip 9.83 /
+//     19.3 against 11.5 / 21.1 ms) — profiles/probe_r05u_walk_policy_short_rt_rows_large.jsonl.
+inline uint32_t on_chip_max_ef(uint32_t stride_floats, size_t index_bytes, bool runtime_geometry) {
     if (stride_floats >= 256u) return 1536u;       // (as far as W and the set fit a wave's LDS: tab_fit in launch_search)
+    if (runtime_geometry && stride_floats <= 64u) return 0u;         // never: see above
+    if (runtime_geometry && stride_floats < 128u) return 160u;
     const int ef = (int)stride_floats * 61 / 25 - 132;
     return (uint32_t)std::min(1536, std::max(index_bytes >= ((size_t)512 << 20) ? 400 : 160, ef));
 }
@@ -1069,9 +1076,11 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const bool quad = tab_fit && !ctx->knobs.classic && nq <= quad_nq;
     const size_t row_bytes = (size_t)ix->n * ix->L.stride * 4;
     const bool long_rows = ix->L.stride >= 256u;
+    const bool rt_rows = !((ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
+                           (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0));   // no compile-time instantiation of the row geometry
     const bool cache_resident = long_rows ? row_bytes < kLongRowOnChipBytes : row_bytes <= kShortRowBitmapBytes;   // "served best by many small waves"
     const bool wide_on_chip = tab_fit && (ctx->knobs.vis_onchip || ctx->knobs.tab_log2 ||
-                                          (ef <= on_chip_max_ef(ix->L.stride, row_bytes) && !cache_resident));
+                                          (ef <= on_chip_max_ef(ix->L.stride, row_bytes, rt_rows) && !cache_resident));
     const bool on_chip = quad || wide_on_chip;
     const uint32_t tab_log2 = on_chip ? tab_fit : 0u;
     a.tab_log2 = tab_log2;
@@ -1091,8 +1100,6 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // Round 5 (profiles/probe_r05r_long_walks_two_waves_other_geometries.jsonl): the same holds for runtime-geometry rows the
     // 256-register tile keeps whole in flight (1M x 384-d: ef 600 / 800 at 79.1 / 105.1 ms against 88.5 / 114.6 ms, ef 400 within
     // 2 %); not for 768-d (fat waves 1 % ahead at ef 400-800) and not for 128-d (thin waves 43 % slower at ef 400).
-    const bool rt_rows = !((ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
-                           (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0));
     const bool w2_geometry = (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) || (rt_rows && ix->L.stride >= 256u && ix->L.nb <= 12u);
     const uint32_t w2_from = ctx->knobs.w2_ef != 0xFFFFFFFFu ? ctx->knobs.w2_ef : (w2_geometry ? kLongWalkEf : 0xFFFFFFFFu);
     const bool w2 = on_chip && q16 && !quad && !ctx->knobs.classic && ef >= w2_from;
