@@ -144,6 +144,17 @@ def _bench_worker(rank, world, port, emu_so, q, scenario, argv):
                 q.put((rank, "ok", {"before": ok_before, "raised": None}))
             except SystemExit as e:
                 q.put((rank, "ok", {"before": ok_before, "raised": str(e)}))
+        elif scenario == "nohost":
+            # the source built from device-resident points and holds no host copy: a host transport cannot replicate it, and EVERY
+            # rank must learn that before the first bulk broadcast (the defect bench's first gloo execution found: the source
+            # skipped an array the others were waiting for)
+            pts = bench.synth(torch, args.n, args.dim, 1, job.dev)
+            hnsw = ida.Hnsw.from_device_points(pts.data_ptr(), args.n, args.dim, ida.Builder().max_batch(1)) if rank == 0 else None
+            try:
+                idd.replicate_index(hnsw, ida.Builder(), src=0)
+                q.put((rank, "ok", {"raised": None}))
+            except RuntimeError as e:
+                q.put((rank, "ok", {"raised": str(e)}))
         dist.barrier()
         dist.destroy_process_group()
     except BaseException as e:  # noqa: BLE001
@@ -229,6 +240,13 @@ def test_bench_corrupted_replica_fails_digest_on_every_rank(world):
     for rank, r in enumerate(res):
         assert r["before"]["all_ranks_identical_to_rank0"]             # the honest replicas pass ...
         assert r["raised"] is not None and "differ from rank 0" in r["raised"], (rank, r)   # ... the bad one stops every rank
+
+
+@pytest.mark.timeout(600)
+def test_host_transport_without_host_points_stops_every_rank():
+    res = _run_world(2, "nohost", TOY + ["--gpus", "2"])
+    for r in res:
+        assert r["raised"] is not None and "host copy of the points" in r["raised"], r
 
 
 def test_bench_wait_for_peers():
