@@ -272,6 +272,8 @@ def parse_args(argv=None):
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child of measure_traffic()
     ap.add_argument("--no-inproc-rccl", action="store_true", help="N > 1: skip the in-process idist_replicate_rccl measurement after the run")
     ap.add_argument("--rccl-child", type=int, default=0, help=argparse.SUPPRESS)        # internal: devices of the in-process replication child
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="--gpus N > 1 started without a launcher: seconds the N ranks get")
+    ap.add_argument("--collective-timeout", type=float, default=900.0, help="bound of every torch.distributed wait (C5 broadcasts 33.8 GB)")
     return ap.parse_args(argv)
 
 
@@ -435,6 +437,8 @@ def phase_timed(job, r, outs, warmup, steps):
     for _ in range(warmup):
         r.run(outs)
     job.sync()
+    if r.nq and getattr(r.search, "_ctx", None) is not None:
+        r.search.filter_counts()                             # reset: what the reject filter does is counted over the K timed steps
     job.barrier()
     job.sync()
     t0 = time.perf_counter()
@@ -447,6 +451,7 @@ def phase_timed(job, r, outs, warmup, steps):
     elapsed = float(job.reduce(elapsed, job.torch.float64, "MAX"))
     if r.nq:
         r.search.check_status()
+        r.filter_counts = r.search.filter_counts()           # (examined, rejected) summed over the K timed launches
     return elapsed
 
 
@@ -582,7 +587,17 @@ def rank0_report(job, args, cfgd, ida, r, outs, hnsw, d_pts, build, m):
     value = nq_total / (elapsed / args.steps)
     kt = search.kernel_times_ms(args.steps)
     ctr = outs[3].cpu().numpy().astype(np.int64)
-    launch_bytes = int((ctr[:, 0] * 4 * dim + ctr[:, 1] * 256 + ctr[:, 2] * 128 + 8 * chosen).sum())
+    # SURVEY 8(d)'s per-query figure: every pushed candidate's f32 row (the reference fetches one per `push`, core/lib.rs:709-710)
+    survey_bytes = int((ctr[:, 0] * 4 * dim + ctr[:, 1] * 256 + ctr[:, 2] * 128 + 8 * chosen).sum())
+    # What THIS kernel's algorithm moves since round 6: wide batches look a candidate up in the one-byte-per-coordinate
+    # copy of its row first (compact row: the stored row + 8 bytes, rounded to 64) and fetch the f32 row only of candidates that copy
+    # cannot reject — push turns the others down without using their distance (core/lib.rs:712-714).  Counted by the kernel itself:
+    # examined / rejected per launch (idist_search_ctx_filter_counts); a candidate pushed while `nearest` is not full skips the filter.
+    info = hnsw.info()
+    examined, rejected = [x / max(args.steps, 1) for x in getattr(r, "filter_counts", (0, 0))]
+    compact_row = (info.row_stride + 8 + 63) // 64 * 64
+    n_dist_launch = int(ctr[:, 0].sum())
+    launch_bytes = int((n_dist_launch - rejected) * 4 * dim + examined * compact_row + (ctr[:, 1] * 256 + ctr[:, 2] * 128 + 8 * chosen).sum())
     kernel_ms = float(kt.mean()) if len(kt) else float("nan")
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
     # HBM bytes per launch: separate `rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE` child passes over this same command (PMC passes
@@ -613,6 +628,16 @@ def rank0_report(job, args, cfgd, ida, r, outs, hnsw, d_pts, build, m):
                              "exceed the 6.29 TB/s streaming-copy rate of the HBM stacks", "mall": mall,
                 "kernel": "search_kernel", "kernel_ms_avg": round(kernel_ms, 3),
                 "alg_bytes_per_launch": launch_bytes, "alg_bytes_per_query": round(launch_bytes / max(nq, 1)),
+                "alg_bytes_how": "f32 rows of the candidates the reject filter did not turn down + compact rows of the candidates it examined "
+                                 "+ adjacency rows + results (kernel counters; = SURVEY 8(d)'s formula when nothing is filtered)",
+                "reject_filter": {"examined_per_launch": round(examined), "rejected_per_launch": round(rejected),
+                                  "rejected_share": round(rejected / examined, 4) if examined else None, "compact_row_bytes": compact_row,
+                                  "pushes_per_launch": n_dist_launch},
+                "survey_8d": {"bytes_per_launch": survey_bytes, "GBps": round(survey_bytes / (kernel_ms * 1e-3) / 1e9, 1),
+                              "over_peak": round(survey_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                              "note": "SURVEY 8(d) books one f32 row per pushed candidate (n_dist*4D + n_exp0*256 + n_expU*128 + 8*ef): the rate a "
+                                      "kernel that fetches them all would need to finish in this time — above the HBM peak means the filter "
+                                      "went below those bytes, not that HBM ran faster"},
                 "n_dist_per_query": round(float(ctr[:, 0].mean()), 1) if nq else 0.0, "n_exp0_per_query": round(float(ctr[:, 1].mean()), 1) if nq else 0.0,
                 "n_expU_per_query": round(float(ctr[:, 2].mean()), 1) if nq else 0.0}
 
@@ -794,9 +819,53 @@ def inproc_rccl_child(args, world, n, dim, chosen):
         return {"skipped": repr(e)[:200]}
 
 
+def self_launch_command(argv, gpus, port):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: the command main() starts itself under — one rank per GPU
+    over RCCL, the driver's own shape (torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def error_line(args, msg):
+    """ONE JSON line for a run that cannot start (rank 0's line has the same leading keys)."""
+    return json.dumps({"metric": "queries/sec @ recall@10>=0.95, 1Mx300-d f32; index build points/sec", "value": None, "unit": "queries/s",
+                       "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": msg[-600:]})
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without WORLD_SIZE / RANK in the environment.  Fails fast with one JSON line when the node has fewer than N
+    devices; otherwise runs the N ranks as a child (bounded), passes rank 0's line through, and prints an error line if none came."""
+    import socket
+    import subprocess
+
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        print(error_line(args, f"--gpus {args.gpus} but {have} MI355X device(s) visible on this node"), flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = self_launch_command(argv, args.gpus, port)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=args.launch_timeout)
+        rc, text = r.returncode, r.stdout
+    except subprocess.TimeoutExpired as e:
+        rc, text = 124, (e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or ""))
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+        return 0 if rc == 0 else rc
+    print(error_line(args, f"torch.distributed.run exited with {rc} and no result line: " + text[-400:]), flush=True)
+    return rc or 1
+
+
 def main():
     args = parse_args()
     cfgd = CONFIGS[args.config]
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and not args.rccl_child:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch
 
@@ -806,17 +875,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: instant_distance_amd has no CPU path")
+        print(error_line(args, f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}"), flush=True)
+        raise SystemExit(2)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        if rank == 0:
+            print(error_line(args, "bench.py needs one MI355X per rank: instant_distance_amd has no CPU path"), flush=True)
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     # Launched by torch.distributed.run (RANK + MASTER_ADDR in the environment): one rank per GPU over RCCL — also at
     # --nproc-per-node 1, where the same replicate / agree / barrier / digest lines run with a world of one.
     if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
+        import datetime
+
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # every collective wait is bounded: a rank that died leaves the others with an error, not a hang
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.collective_timeout))
     job = Job(torch, rank, world, local_rank, dev, dist)
     out = run_bench(job, args)
     if args.traffic_child:
@@ -828,10 +903,13 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         if job.multi and not args.no_inproc_rccl:
-            gone, waited = wait_for_peers(pids)
-            child = inproc_rccl_child(args, world, out["config"]["n"], out["config"]["dim"], out["config"]["ef_search"])
-            child["peer_ranks_exited_before_launch"] = gone
-            child["waited_for_peers_s"] = waited
+            try:
+                gone, waited = wait_for_peers(pids)
+                child = inproc_rccl_child(args, world, out["config"]["n"], out["config"]["dim"], out["config"]["ef_search"])
+                child["peer_ranks_exited_before_launch"] = gone
+                child["waited_for_peers_s"] = waited
+            except Exception as e:  # noqa: BLE001 — the line is printed whatever the in-process RCCL child does
+                child = {"error": repr(e)[:300]}
             out["config"]["replicate_rccl_in_process"] = child
         print(json.dumps(out), flush=True)
 

@@ -244,6 +244,13 @@ idist_status idist_search_batch_device(const idist_index* idx, idist_search_ctx*
 idist_status idist_search_ctx_status(idist_search_ctx* ctx);
 /* IDIST_TIES_DROP only: *out = 1 if a search since the last call exceeded the tie capacity (then reset). */
 idist_status idist_search_ctx_tie_overflowed(idist_search_ctx* ctx, int32_t* out);
+/* Diagnostics of the walk's reject filter: wide batches on indexes the filter applies to look every new
+ * candidate up in a one-byte-per-coordinate copy of the rows first and fetch the f32 row only of those that copy cannot prove to
+ * lie beyond `nearest`'s furthest entry — the candidates `Search::push` turns down at core/lib.rs:712-714 without using their
+ * distance.  Results and the counters of idist_search_batch are the reference's either way; these two numbers say how many
+ * candidates the filter examined and how many f32 rows it spared, summed over the searches of this context since the last
+ * reset (bench.py derives the bytes a launch really requests from them).  Synchronise the context's stream first. */
+idist_status idist_search_ctx_filter_counts(idist_search_ctx* ctx, uint64_t* examined, uint64_t* rejected, int32_t reset);
 /* HIP-event duration of the last search kernel launched through ctx, milliseconds. */
 idist_status idist_search_ctx_last_kernel_ms(idist_search_ctx* ctx, float* ms);
 /* Durations (ms) of the most recent search-kernel launches through ctx, oldest first, measured

@@ -108,6 +108,7 @@ SYMBOLS = {
     "idist_search_batch_device": (C.c_int32, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "idist_search_ctx_status": (C.c_int32, [_vp]),
     "idist_search_ctx_tie_overflowed": (C.c_int32, [_vp, C.POINTER(C.c_int32)]),
+    "idist_search_ctx_filter_counts": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
     "idist_search_ctx_last_kernel_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
     "idist_search_ctx_kernel_times": (C.c_int32, [_vp, _f32p, C.c_uint32, _u32p]),
     "idist_replicate": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(_vp)]),

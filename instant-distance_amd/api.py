@@ -249,6 +249,15 @@ class Search:
         _lib().check(_lib().idist_search_ctx_tie_overflowed(self._ctx, C.byref(out)))
         return bool(out.value)
 
+    def filter_counts(self, reset: bool = True) -> tuple[int, int]:
+        """(candidates the walk's reject filter examined, f32 rows it spared) over this Search's launches since the last reset —
+        diagnostics; results never depend on the filter.  Synchronise first."""
+        if self._ctx is None:
+            return 0, 0
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _lib().check(_lib().idist_search_ctx_filter_counts(self._ctx, C.byref(a), C.byref(b), 1 if reset else 0))
+        return int(a.value), int(b.value)
+
     def check_status(self):
         """Raise if a device-side guard tripped during the launches so far (after a stream sync)."""
         _lib().check(_lib().idist_search_ctx_status(self._ctx))

@@ -190,6 +190,11 @@ struct idist_index {
     uint64_t* d_layer_off = nullptr;
     int n_cu = 256;
     idist_build_stats stats{};
+    // the walk's reject filter (FilterView, idist_device.hpp): a compact copy of the rows, made once — after a build / an import, or
+    // on the first search of an index whose buffers were filled from outside (idist_index_alloc + a broadcast) — see filter_ensure
+    mutable std::mutex filt_mu;
+    mutable std::atomic<int> filt_state{0};    // 0 not made yet, 1 ready, 2 not available (no memory: the walks run without it)
+    mutable idist::FilterView filt{};
 
     IndexView view() const {
         IndexView v;
@@ -205,6 +210,7 @@ struct idist_index {
         v.tail = L.tail;
         v.n_upper = n_upper;
         v.metric = (uint32_t)cfg.metric;
+        if (filt_state.load(std::memory_order_acquire) == 1) v.f = filt;
         return v;
     }
 };
@@ -228,6 +234,8 @@ struct Knobs {
                                   // word the kernel writes to the context's pinned buffer (A/B knob)
     bool tie_spill_first = false; // IDIST_TIE_SPILL=1: strict ties go to the HBM bags at the first overflow instead of growing the LDS region first (test knob)
     bool events = true;           // IDIST_KERNEL_EVENTS=0: no HIP events around the search kernels (idist_search_ctx_kernel_times then has nothing)
+    bool filter = true;           // IDIST_FILTER=0: wide on-chip walks without the reject filter (test / A-B knob)
+    uint32_t filter_waves = 0;    // IDIST_FILTER_WAVES=1|2: waves per SIMD of the filtered wide walk (0 = the policy's choice; A-B knob)
     bool tab_ids = false;         // IDIST_TAB_FORMAT=ids: the on-chip set always keeps full ids (4 per bucket, frozen at 7/8), never
                                   // 16-bit quotients (8 per bucket, single ids overflow) (test / A-B knob)
     bool tab_q16 = false;         // IDIST_TAB_FORMAT=q16: quotients wherever they apply, also where the policy would keep ids
@@ -244,6 +252,8 @@ struct Knobs {
         if (const char* e = test_env("IDIST_QUAD_NQ")) k.quad_nq = (uint32_t)std::min<unsigned long>(strtoul(e, nullptr, 10), 0xFFFFFFFEul);
         if (const char* e = test_env("IDIST_WALK")) k.classic = e[0] == 'c';      // (honoured by the test build only, see variants_check)
         if (const char* e = test_env("IDIST_BLOOM")) k.bloom = e[0] != '0';
+        if (const char* e = test_env("IDIST_FILTER")) k.filter = e[0] != '0';
+        if (const char* e = test_env("IDIST_FILTER_WAVES")) k.filter_waves = (uint32_t)std::min(2, std::max(0, atoi(e)));
         if (const char* e = test_env("IDIST_VISITED")) { k.vis_bitmap = e[0] == 'b'; k.vis_onchip = e[0] == 'o'; }
         if (const char* e = test_env("IDIST_NO_ZERO_COPY")) k.no_zero_copy = e[0] != '0';
         if (const char* e = test_env("IDIST_TAB_FORMAT")) { k.tab_ids = e[0] == 'i'; k.tab_q16 = e[0] == 'q'; }
@@ -263,7 +273,7 @@ struct idist_search_ctx {
     uint32_t slots = 0;            // query slots currently backed by a visited bitmap
     VisGeom vis{};
     uint32_t* d_visited = nullptr; // [slots][vis.slot_words], all-zero between launches
-    uint32_t* d_next = nullptr;    // [0] queue head, [1] status
+    uint32_t* d_next = nullptr;    // [0] queue head, [1] status, [2] completion count, [16..19] the reject filter's two 64-bit counters
     uint32_t queue_base = 0;       // value of the queue head before the next launch (it is never reset: each launch of nq queries on
                                    // g workgroups moves it by nq + g, unsigned wrap-around included)
     // narrow host-pointer batches (the reference's one query per call): query and results cross PCIe through one pinned,
@@ -747,7 +757,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             // a sequential step (B = 1: the top layer, the first 63 points) depends on the whole previous step anyway: all of its
             // launches go to the update stream — same-stream boundaries (~2 us) instead of three cross-stream event hops (~27 us each
             // in the trace of profiles/trace_chain_r05b_build_c2.json: 74 of the 179 us such a step took)
-            const bool seq1 = pipe && B == 1;
+            // Only where every descent stream has its own queue head, visited bitmaps and tie bags (two_a): with ONE set of them (a build
+            // on the HBM tie bags, IDIST_BUILD_STREAMS=off) the last sequential step's descent on s2 and the next, concurrent step's
+            // descent on s1 — which waits for the step BEFORE it only — would share them.
+            const bool seq1 = pipe && two_a && B == 1;
             hipStream_t sA = pipe ? (seq1 ? s2 : (two_a && alt && par ? s3 : s1)) : stream, sS = pipe ? s2 : stream;
             IndexView viewA = view, viewS = view;
             BuildArgs aA = a;
@@ -1035,6 +1048,7 @@ inline uint32_t on_chip_max_ef(uint32_t stride_floats, size_t index_bytes, bool 
 constexpr size_t kShortRowBitmapBytes = (size_t)320 << 20;
 // ... and long rows by the on-chip walk from this size on (below it nothing was measured: the round-2 rule stands)
 constexpr size_t kLongRowOnChipBytes = (size_t)96 << 20;
+constexpr uint32_t kFilterWaves = 2u;    // waves per SIMD of a filtered wide walk (launch_search)
 constexpr uint32_t kLongWalkEf = 512u;   // ef_search from which wide on-chip batches run two thinner waves per SIMD (see launch_search)
 
 // Long walks and where the visited bitmaps land (round 5, measured, nothing kept): ef_search 800 at 1M points test-and-sets the HBM
@@ -1047,6 +1061,74 @@ constexpr uint32_t kLongWalkEf = 512u;   // ef_search from which wide on-chip ba
 // fast one on one box (four of five processes at 74-76 ms) and none on the next (five of five at 82.7 ms) for ~0.2 s per context: not
 // kept.  Gathering the rows with the non-temporal hint (leaving the cache to the bitmaps) costs 11-15 % at every ef_search and 30 % of
 // the build (`make nt`, profiles/probe_r05e_rows_nontemporal_ab_c3.jsonl): the row gathers live on Infinity-Cache hits too.
+// The compact copy of the rows behind the walk's reject filter (FilterView): made once per index, here.  The lattice [lo, lo + 255
+// step] comes from a sample of the rows (mean +- 5 sigma of the coordinates, clipped to the sample's range): its choice decides how
+// many candidates the filter can reject, never a result — a coordinate outside it is clamped and its error is part of the row's
+// recorded |p - p^|.  Runs on the null stream and waits for it (an index is immutable once it is searched; its rows are in place).
+// Geometries the search kernels have no filter tile for (compact rows beyond four 128-B chunks without a compile-time instantiation)
+// and indexes the copy finds no memory for simply run without it.
+bool filter_applies(const idist_index* ix) {
+    const bool tmpl = (ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
+                      (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0);
+    return ix->n > 0 && (tmpl || filt_stride(ix->L.stride) <= 128u * (uint32_t)kFiltRtChunks);
+}
+idist_status filter_ensure(const idist_index* ix) {
+    if (ix->filt_state.load(std::memory_order_acquire) != 0) return IDIST_OK;
+    std::lock_guard<std::mutex> lk(ix->filt_mu);
+    if (ix->filt_state.load(std::memory_order_acquire) != 0) return IDIST_OK;
+    if (!filter_applies(ix)) { ix->filt_state.store(2, std::memory_order_release); return IDIST_OK; }
+    HIPCHK(hipSetDevice(ix->device));
+    const uint32_t stride = ix->L.stride, fs = filt_stride(stride);
+    // sample: up to 2048 rows, evenly spaced
+    const uint32_t ns = std::min<uint32_t>(ix->n, 2048u), every = ix->n / ns;
+    std::vector<float> smp((size_t)ns * stride);
+    HIPCHK(hipMemcpy2D(smp.data(), (size_t)stride * 4, ix->d_points, (size_t)every * stride * 4, (size_t)stride * 4, ns, hipMemcpyDeviceToHost));
+    double sum = 0.0, sum2 = 0.0, mn = 0.0, mx = 0.0;
+    size_t cnt = 0;
+    for (uint32_t r = 0; r < ns; r++)
+        for (uint32_t pos = 0; pos < stride; pos++) {
+            if (natural_pos(pos, ix->L.nb) >= ix->dim) continue;
+            const double v = smp[(size_t)r * stride + pos];
+            if (!(std::fabs(v) <= 3.0e38)) continue;
+            if (!cnt || v < mn) mn = v;
+            if (!cnt || v > mx) mx = v;
+            sum += v; sum2 += v * v; cnt++;
+        }
+    double lo = 0.0, hi = 1.0;
+    if (cnt) {
+        const double mean = sum / (double)cnt, sd = std::sqrt(std::max(0.0, sum2 / (double)cnt - mean * mean));
+        lo = std::max(mn - 0.25 * sd, mean - 5.0 * sd);
+        hi = std::min(mx + 0.25 * sd, mean + 5.0 * sd);
+    }
+    if (!(hi > lo) || !((hi - lo) / 65280.0 > 1e-30)) hi = lo + 1.0;      // degenerate data: any lattice is as good
+    FilterView f{};
+    f.fstride = fs;
+    f.lo = (float)lo;
+    f.step256 = (float)((hi - lo) / 65280.0);                            // 255 steps of 256 sub-steps
+    f.qscale = 1.0f / f.step256;
+    f.dscale = f.step256 * f.step256;
+    // every float step of the test (the conversion of I, dscale, the sums, the canonical chain of dim / 8 + 7 roundings) is covered
+    f.up = 1.0f + 4.8828125e-4f + 6.0e-8f * (float)(ix->L.stride / 8u + 8u);
+    f.slack = 4.8e-7f * std::sqrt((float)ix->dim);
+    uint8_t* rows = nullptr;
+    if (hipMalloc((void**)&rows, (size_t)ix->n * fs) != hipSuccess) {
+        (void)hipGetLastError();
+        ix->filt_state.store(2, std::memory_order_release);
+        return IDIST_OK;
+    }
+    const uint32_t grid = std::min<uint32_t>(ix->n, (uint32_t)ix->n_cu * 32u);
+    IDIST_LAUNCH(filter_rows_kernel, grid, 64, 0, nullptr, ix->d_points, ix->n, ix->dim, stride, ix->L.nb, rows, fs, f.lo, f.step256);
+    if (hipDeviceSynchronize() != hipSuccess) {
+        const hipError_t e = hipGetLastError();
+        hipFree(rows);
+        return fail(IDIST_ERR_HIP, "filter_rows_kernel failed: %s", hipGetErrorString(e));
+    }
+    f.rows = rows;
+    ix->filt = f;
+    ix->filt_state.store(1, std::memory_order_release);
+    return IDIST_OK;
+}
+
 idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const float* d_q, uint32_t nq,
                            uint32_t* d_pid, float* d_dist, uint32_t* d_cnt, uint32_t* d_ctr, hipStream_t stream,
                            uint32_t* status_host = nullptr, uint32_t* grid_out = nullptr, uint32_t* done_host = nullptr, uint32_t done_seq = 0) {
@@ -1079,10 +1161,32 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const bool rt_rows = !((ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
                            (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0));   // no compile-time instantiation of the row geometry
     const bool cache_resident = long_rows ? row_bytes < kLongRowOnChipBytes : row_bytes <= kShortRowBitmapBytes;   // "served best by many small waves"
+    // With the reject filter in front (round 6) the on-chip walk stays ahead at every ef_search the set fits — 1M x 128 at ef 200 / 400:
+    // 8.5 / 15.4 ms against 10.6 / 20.8 ms on the bitmap walk, 4M x 64-d at ef 100 / 200: 5.1 / 10.3 against 5.9 / 11.8 — and the ef
+    // caps of on_chip_max_ef only bind for unfiltered indexes (compact rows beyond the filter's tiles, IDIST_FILTER=0).  Cache-resident
+    // short rows are a tie (C2: 3.62 against 3.85 ms at ef 100, 6.86 against 6.63 at ef 200) and keep the bitmap walk
+    // (profiles/probe_r06f_filter_policy.jsonl).
+    const bool filter_ok = ctx->knobs.filter && filter_applies(ix);
     const bool wide_on_chip = tab_fit && (ctx->knobs.vis_onchip || ctx->knobs.tab_log2 ||
-                                          (ef <= on_chip_max_ef(ix->L.stride, row_bytes, rt_rows) && !cache_resident));
+                                          ((filter_ok || ef <= on_chip_max_ef(ix->L.stride, row_bytes, rt_rows)) && !cache_resident));
     const bool on_chip = quad || wide_on_chip;
-    const uint32_t tab_log2 = on_chip ? tab_fit : 0u;
+    uint32_t tab_log2 = on_chip ? tab_fit : 0u;
+    // The reject filter in front of the wide on-chip walks' distance passes (its compact rows are made on first use).  A filtered
+    // walk is bound by its dependent round trips, so it runs as `fw` thin waves per SIMD (walk_thin_filter, idist_device.hpp) with
+    // the largest quotient set that lets 4 * fw of them share a CU's LDS — where the quotient form applies (n <= 33M) and the
+    // caller did not pin the set's form or size.
+    const bool use_filter = wide_on_chip && !quad && filter_ok;
+    if (use_filter) CHK(filter_ensure(ix));
+    const bool filtered = use_filter && ix->filt_state.load(std::memory_order_acquire) == 1;
+    uint32_t fw = 1;
+    if (filtered && !ctx->knobs.classic && !ctx->knobs.tab_ids) fw = ctx->knobs.filter_waves ? ctx->knobs.filter_waves : kFilterWaves;
+    if (fw > 1) {
+        uint32_t l = ctx->knobs.tab_log2 ? std::min(tab_fit, ctx->knobs.tab_log2) : tab_fit;
+        while (l > 10u && smem_bytes(ix->L.stride, a.wcap, false, 1u << l, a.vis.dirty_words, false) * 4u * fw > (size_t)160 * 1024) l--;
+        if (q16_applies(l, q16_universe_bits(ix->n, l))) tab_log2 = l;
+        else fw = 1;
+    }
+    const bool thin = fw > 1;
     a.tab_log2 = tab_log2;
     // the set stores 16-bit quotients (twice the ids in the same LDS) whenever n allows it: up to 33M points with 32 KB
     a.ubits = on_chip ? q16_universe_bits(ix->n, tab_log2) : 0u;
@@ -1090,7 +1194,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // stays below the 7/8 * 2^tab_log2 ids the plain set takes, the plain set never spills and its cheaper probe wins by
     // 1-2 % (ef_search = 100: 10.25 vs 10.42 ms per 10k queries at C3, profiles/r03/probe_r03a_ef_paths_*)
     const bool ids_suffice = 53u * ef + 600u <= (7u << tab_log2) / 8u;
-    const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits) && (ctx->knobs.tab_q16 || ctx->knobs.tab_log2 || !ids_suffice);
+    const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits) && (thin || ctx->knobs.tab_q16 || ctx->knobs.tab_log2 || !ids_suffice);
     // Long walks (ef_search in the hundreds): an expansion costs a wave 9-10 us whatever it fetches, and it fetches fewer new rows
     // the longer the walk runs — more, thinner waves (two 256-register waves per SIMD, as many as the CU's LDS holds) keep more
     // expansions in flight than one fat wave per SIMD.
@@ -1102,9 +1206,10 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // 2 %); not for 768-d (fat waves 1 % ahead at ef 400-800) and not for 128-d (thin waves 43 % slower at ef 400).
     const bool w2_geometry = (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) || (rt_rows && ix->L.stride >= 256u && ix->L.nb <= 12u);
     const uint32_t w2_from = ctx->knobs.w2_ef != 0xFFFFFFFFu ? ctx->knobs.w2_ef : (w2_geometry ? kLongWalkEf : 0xFFFFFFFFu);
-    const bool w2 = on_chip && q16 && !quad && !ctx->knobs.classic && ef >= w2_from;
+    const bool w2 = on_chip && q16 && !quad && !thin && !ctx->knobs.classic && ef >= w2_from;
     const uint32_t w2_per_cu = (uint32_t)std::min<size_t>(8, (size_t)160 * 1024 / smem_bytes(ix->L.stride, a.wcap, false, 1u << std::max(tab_log2, 5u), a.vis.dirty_words));
-    uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (w2 ? std::max(w2_per_cu, 4u) : (on_chip ? 4u : 16u)));   // quad: two workgroups per CU where registers allow
+    const uint32_t thin_per_cu = (uint32_t)std::min<size_t>(4u * fw, (size_t)160 * 1024 / smem_bytes(ix->L.stride, a.wcap, false, 1u << std::max(tab_log2, 5u), a.vis.dirty_words, false));
+    uint32_t resident = (uint32_t)ix->n_cu * (quad ? 2u : (thin ? std::max(thin_per_cu, 4u) : (w2 ? std::max(w2_per_cu, 4u) : (on_chip ? 4u : 16u))));   // quad: two workgroups per CU where registers allow
     if (ctx->tie_spill) {
         // one bag of n keys per slot (a walk can hold every point as a tie at most once); the slots that fit 1 GiB
         const uint32_t fit = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)std::max(ix->n, 1u) * 8));
@@ -1134,15 +1239,17 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const bool lat = !on_chip && nq <= ctx->knobs.latency_nq &&
                      smem_bytes(ix->L.stride, a.wcap, false, kBloomLatWords, a.vis.dirty_words) <= 64 * 1024;
     const size_t smem = smem_bytes(ix->L.stride, a.wcap, false, on_chip ? (1u << tab_log2) : (lat ? kBloomLatWords : kBloomWords),
-                                   a.vis.dirty_words);
+                                   a.vis.dirty_words, !thin);
     if (smem > 64 * 1024) return fail(IDIST_ERR_INVALID_ARG, "dim/ef_search need %zu B of LDS per wave (> 64 KiB)", smem);
     const uint32_t grid = std::min(std::min(nq, ctx->slots), resident);
     [[maybe_unused]] const bool classic = ctx->knobs.classic;   // (test build: IDIST_VARIANT_SEARCH_*)
     IndexView view = ix->view();
+    if (!filtered) view.f = FilterView{};
     a.queue_base = ctx->queue_base;
     a.status_host = status_host && grid <= idist_search_ctx::kIoStatusSlots ? status_host : nullptr;
     a.done_host = done_host;
     a.done_count = ctx->d_next + 2;
+    a.filt_counts = reinterpret_cast<unsigned long long*>(ctx->d_next + 16);
     a.done_seq = done_seq;
     if (grid_out) *grid_out = grid;
     const uint32_t slot = (uint32_t)(ctx->n_launch % IDIST_EVENT_RING);
@@ -1153,12 +1260,12 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
 #ifdef IDIST_VARIANTS
 #define IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_)                                                    \
     else if (on_chip && classic && q16) {                                                                   \
-        auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true, false, true)>;  \
+        auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkClassic, 0, false, 1, true, false, true))>;  \
         IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                                  \
     }
 #define IDIST_VARIANT_SEARCH_ONCHIP_IDS(NB_, RS_, TAIL_)                                                    \
     else if (on_chip && classic) {                                                                          \
-        auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>;               \
+        auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkClassic, 0, false, 1, true))>;               \
         IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                                  \
     }
 #define IDIST_VARIANT_SEARCH_BITMAP(NB_, RS_, TAIL_)                                                        \
@@ -1179,14 +1286,17 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
         } else if (quad) {                                                                         \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, true)>; \
             IDIST_LAUNCH(kS, grid, 256, smem, stream, view, a);                                    \
+        } else if (thin) {                                                                         \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_thin_filter(2)>;                         \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_) else if (w2) {                          \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true))>; \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } else if (on_chip && q16) {                                                               \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true, false, true))>; \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } IDIST_VARIANT_SEARCH_ONCHIP_IDS(NB_, RS_, TAIL_) else if (on_chip) {                     \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true)>;  \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true))>;  \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } else if (lat) {                                                                          \
             auto kS = search_kernel<NB_, RS_, TAIL_, kWalkLatency>;                                \
@@ -1466,6 +1576,7 @@ void idist_index_free(idist_index* idx) {
     hipFree(idx->d_zero);
     hipFree(idx->d_upper);
     hipFree(idx->d_layer_off);
+    hipFree(const_cast<uint8_t*>(idx->filt.rows));
     delete idx;
 }
 
@@ -1574,6 +1685,16 @@ idist_status idist_search_ctx_status(idist_search_ctx* ctx) {
         g_tie_cap_msg = cap;
     }
     return device_status_to_code(st, ctx->tie_policy);
+}
+
+idist_status idist_search_ctx_filter_counts(idist_search_ctx* ctx, uint64_t* examined, uint64_t* rejected, int32_t reset) {
+    if (!ctx) return fail(IDIST_ERR_INVALID_ARG, "ctx is null");
+    unsigned long long c[2] = {0, 0};
+    HIPCHK(hipMemcpy(c, ctx->d_next + 16, sizeof(c), hipMemcpyDeviceToHost));   // (waits for the null stream only: synchronise first)
+    if (reset) HIPCHK(hipMemset(ctx->d_next + 16, 0, sizeof(c)));
+    if (examined) *examined = c[0];
+    if (rejected) *rejected = c[1];
+    return IDIST_OK;
 }
 
 idist_status idist_search_ctx_tie_overflowed(idist_search_ctx* ctx, int32_t* out) {

@@ -48,6 +48,26 @@ constexpr uint64_t kMaxKey = 0x7fffffffffffffffull;
 
 enum : uint32_t { kStTieOverflow = 1u, kStGuard = 2u, kStBadRow = 4u, kStQueue = 8u };
 
+// The walk's reject filter (search only): a second, compact copy of the point rows — one byte per stored float on a fixed
+// lattice p^_k = lo + step * u_k, u_k in [0, 255], in the f32 rows' own (blocked) element order, 8 bytes of row metadata at the
+// end of the row {|p - p^|_2 rounded up (f32), sum u_k^2 (u32)}.  `Search::push` (core/lib.rs:704-720) needs the distance of a
+// candidate only when it ACCEPTS it (`Err(idx) if idx < ef`); for the others a proof that the canonical distance exceeds
+// nearest[ef-1]'s is enough, and  |q - p| >= |q^ - p^| - |q - q^| - |p - p^|  gives one from the compact row alone: |q^ - p^|^2
+// is an exact integer (v_dot4_u32_u8 of the row's bytes with the query's 16-bit lattice coordinates).  Rows it cannot reject are
+// fetched in f32 as before; accepted candidates carry the canonical distance, n_dist counts every push — same ids, same order,
+// same distance bits, same counters (filter_rounds below).
+struct FilterView {
+    const uint8_t* rows = nullptr;   // [n][fstride], nullptr = no filter
+    uint32_t fstride = 0;            // bytes per compact row: stride codes + 8 bytes of metadata, rounded up to 64
+    float lo = 0.0f, step256 = 0.0f; // lattice: p^ = lo + (256 u) * step256, q^ = lo + Q * step256 (Q: 16 bits)
+    float qscale = 0.0f;             // 1 / step256
+    float dscale = 0.0f;             // step256^2: |q^ - p^|^2 = I * dscale
+    float up = 1.0f;                 // safety factor > 1 on the threshold side (rounding of every float step, of the canonical sum)
+    float slack = 0.0f;              // absolute slack of a query's own lattice error (f32 evaluation), per sqrt(dim) * magnitude
+};
+constexpr uint32_t filt_stride(uint32_t stride_floats) { return (stride_floats + 8u + 63u) & ~63u; }
+constexpr int kFiltRtChunks = 4;     // runtime-geometry rows: filtered while a compact row fits four 128-B chunks (dim <= 496)
+
 // Device view of an index (plain pointers; lives in kernel arguments).
 struct IndexView {
     const float* points;      // [n][stride] blocked rows
@@ -60,7 +80,17 @@ struct IndexView {
     uint32_t tail;            // 1 if a 4-wide tail follows (padded dim % 8 == 4)
     uint32_t n_upper;
     uint32_t metric;          // 0 = squared L2, 1 = L2
+    FilterView f;             // compact copy of the rows for the walk's reject filter (search kernels only)
 };
+
+// natural element of stored position `pos` (inverse of blocked_pos)
+__host__ __device__ inline uint32_t natural_pos(uint32_t pos, uint32_t nb) {
+    if (pos < 32u * nb) {
+        const uint32_t t = pos >> 5, r = pos & 31u, j = r >> 2, c = r & 3u;
+        return (t << 5) + (c << 3) + j;
+    }
+    return pos;
+}
 
 // Position of natural element e inside a blocked row.
 __host__ __device__ inline uint32_t blocked_pos(uint32_t e, uint32_t nb) {
@@ -556,7 +586,8 @@ constexpr int rounds_in_flight() {
 #ifndef IDIST_RT2_BLOCKS
 #define IDIST_RT2_BLOCKS 6
 #endif
-template <int WALK> constexpr int rt_rounds() { return walk_waves(WALK) == 1 ? 4 : (walk_waves(WALK) == 2 ? IDIST_RT2_ROUNDS : 1); }
+constexpr bool walk_is_thin(int code) { return ((code >> 20) & 1) != 0; }   // (walk_thin, defined with the reject filter below)
+template <int WALK> constexpr int rt_rounds() { return walk_is_thin(WALK) ? 1 : (walk_waves(WALK) == 1 ? 4 : (walk_waves(WALK) == 2 ? IDIST_RT2_ROUNDS : 1)); }
 template <int WALK> constexpr int rt_blocks() { return walk_waves(WALK) == 1 ? 8 : (walk_waves(WALK) == 2 ? IDIST_RT2_BLOCKS : 4); }
 template <int NB, int RS, int TAIL, int WALK, class Mid = NoMid>
 __device__ __forceinline__ void dist_rounds_walk(const IndexView& ix, const float* q, const uint32_t* act_pid,
@@ -567,7 +598,8 @@ __device__ __forceinline__ void dist_rounds_walk(const IndexView& ix, const floa
         dist_rounds_inflight<NB, RS, TAIL, RIF, !walk_q_lds(WALK), 8, Mid, walk_ea(WALK)>(ix, natural_view(q, NB), act_pid, act_dist, na, 0, mid, thr_bits);
         return;
     }
-    if constexpr (NB < 0 && walk_mode(WALK) != kWalkClassic) {
+    if constexpr ((NB < 0 || (walk_is_thin(WALK) && NB > 12)) && walk_mode(WALK) != kWalkClassic) {
+        // (thin filtered walks on long compile-time rows take the chunked tile too: a whole 768-d row is 96 registers per lane)
         if (na <= 0) mid();
         dist_rounds_inflight_rt<rt_blocks<WALK>(), rt_rounds<WALK>()>(ix, natural_view(q, (int)ix.nb), act_pid, act_dist, na, 0, mid);
     } else if constexpr (RIF > 1 || (walk_rif(WALK) == 1 && NB >= 0)) {
@@ -577,6 +609,200 @@ __device__ __forceinline__ void dist_rounds_walk(const IndexView& ix, const floa
         mid();
         dist_rounds<NB, RS, TAIL>(ix, q, act_pid, act_dist, na);
     }
+}
+
+// ---------------------------------------------------------------------------
+// The walk's reject filter (FilterView above).  Walk-code bit 19 compiles it in.
+// ---------------------------------------------------------------------------
+constexpr int kWalkFilterBit = 1 << 19;
+constexpr bool walk_filter(int code) { return (code & kWalkFilterBit) != 0; }
+constexpr int walk_with_filter(int code) { return code | kWalkFilterBit; }
+// Thin filtered walks (bit 20).  With the filter in front an expansion moves ~21 KB instead of ~62 KB (C3) and the walk is bound by
+// its dependent round trips, not by bytes: what helps is MORE walks per CU, each with less state — two or three waves per SIMD, the
+// f32 pass one round of 8 rows at a time (a filtered expansion keeps ~4 rows), the query fragment read from LDS, no hand-over block
+// of the four-wave walk in LDS, a smaller on-chip visited set.  (C3 ef 100, 10k queries: one wave per SIMD 7.6 ms, two 5.9 ms;
+// profiles/probe_r06c_filter_waves_c3.jsonl.)
+constexpr int kWalkThinBit = 1 << 20;
+constexpr bool walk_thin(int code) { return (code & kWalkThinBit) != 0; }
+constexpr int walk_thin_filter(int waves = 2) {  // the walk code of a thin filtered walk at `waves` per SIMD: quotient set, one f32 round in flight
+    return walk_code(kWalkOverlap, 1, true, waves, true, false, true) | kWalkFilterBit | kWalkThinBit;
+}
+// 128-B chunks of a compact row (8 lanes x 16 B each; the last one may be half a chunk)
+template <int NB, int RS, int TAIL>
+constexpr int filt_chunks() {
+    if (NB < 0) return kFiltRtChunks;
+    const uint32_t used = 32u * (uint32_t)NB + 8u * (uint32_t)RS + 4u * (uint32_t)TAIL;
+    const uint32_t stride = used < 16u ? 16u : ((used + 15u) & ~15u);
+    return (int)((filt_stride(stride) + 127u) / 128u);
+}
+// rows of one filter pass in flight: 8 * FR, bounded by the registers a row's bytes take (4 * NCH per lane)
+template <int NCH, int WALK> constexpr int filt_rounds() {
+    const int budget = walk_waves(WALK) == 1 ? 256 : 56;
+    const int r = budget / (4 * NCH);
+    return r > 8 ? 8 : (r < 2 ? 2 : r);
+}
+
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef IDIST_EMU
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
+    return c;
+#else
+    return __builtin_amdgcn_udot4(a, b, c, false);        // v_dot4_u32_u8
+#endif
+}
+// sum over the 8 lanes of a group, valid in lane j == 0 (the fold's moves: row_shl:4, quad_perm [2,3,0,1], [1,0,3,2])
+__device__ __forceinline__ uint32_t group_sum_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    return v;
+}
+
+// A query on the filter's lattice, held in registers for the whole walk: lane j of every 8-lane group keeps the bytes of the
+// positions its loads of a compact row cover (chunk c: positions 128 c + 16 j ... + 15) — the 16-bit coordinate Q split into a
+// high and a low byte plane, so that sum Q u = 256 (h . u) + (l . u) is two v_dot4_u32_u8 per dword of row.
+template <int NCH>
+struct FilterQ {
+    uint4 h[NCH], l[NCH];
+    float eq = 0.0f;        // |q - q^|_2, rounded up (NaN for a query with a NaN coordinate: nothing is ever rejected)
+    uint64_t sq = 0;        // sum Q^2
+    bool on = false;
+    mutable uint32_t seen = 0, rejected = 0;   // per walk; search_kernel adds them to the context's counters when the query ends
+};
+template <int NCH>
+__device__ __forceinline__ void filter_stage_query(const IndexView& ix, const float* q, FilterQ<NCH>& fq) {
+    fq.on = ix.f.rows != nullptr && ix.f.fstride <= 128u * (uint32_t)NCH;
+    if (!fq.on) return;
+    const int j = lane_id() & 7;
+    float e2 = 0.0f, mx = 0.0f;
+    uint32_t sq_lo = 0, sq_hi = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        uint32_t hw[4] = {0u, 0u, 0u, 0u}, lw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            const uint32_t pos = 128u * (uint32_t)c + 16u * (uint32_t)j + (uint32_t)b;
+            if (pos < ix.stride && natural_pos(pos, ix.nb) < ix.dim) {       // (padding: Q = u = 0 by construction, no error either side)
+                const float v = q[pos];
+                const float t = (v - ix.f.lo) * ix.f.qscale;
+                const float r = __builtin_rintf(__builtin_fminf(__builtin_fmaxf(t, 0.0f), 65535.0f));   // fmax(NaN, 0) = 0
+                const uint32_t Q = (uint32_t)r;
+                const float e = v - __builtin_fmaf((float)Q, ix.f.step256, ix.f.lo);                     // NaN / inf for such a v
+                e2 = __builtin_fmaf(e, e, e2);
+                mx = __builtin_fmaxf(mx, __builtin_fabsf(v));
+                const uint32_t qq = Q * Q;
+                sq_hi += (sq_lo + qq < sq_lo) ? 1u : 0u;
+                sq_lo += qq;
+                hw[b >> 2] |= (Q >> 8) << (8 * (b & 3));
+                lw[b >> 2] |= (Q & 255u) << (8 * (b & 3));
+            }
+        }
+        fq.h[c] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        fq.l[c] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+    // the 8 lanes of a group cover the row once: totals over the group (every group computes the same)
+    uint64_t sq = ((uint64_t)sq_hi << 32) | sq_lo;
+    for (int m = 1; m <= 4; m <<= 1) {
+        e2 += __shfl_xor(e2, m, 64);
+        const float o = __shfl_xor(mx, m, 64);
+        mx = __builtin_fmaxf(mx, o);
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)sq, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(sq >> 32), m, 64);
+        sq += ((uint64_t)hi << 32) | lo;
+    }
+    fq.sq = sq;
+    // |q - q^| as evaluated in f32: each term is off by at most ~2^-22 of the magnitudes involved
+    const float mag = mx + __builtin_fabsf(ix.f.lo) + 65536.0f * ix.f.step256;
+    fq.eq = __builtin_sqrtf(e2) * 1.001f + ix.f.slack * mag;
+}
+
+// One filter pass over act_pid[0..na): act_dist[k] = kAbandoned where the compact row PROVES that the canonical distance
+// exceeds the threshold (st = sqrt of the furthest distance of a full `nearest` for squared L2, the distance itself for L2),
+// 0 otherwise.  8 lanes per row like the f32 gather; FR rounds of 8 rows are requested before the first is consumed.
+template <int NCH, int FR, class Mid = NoMid>
+__device__ __forceinline__ void filter_rounds(const IndexView& ix, const FilterQ<NCH>& fq, const uint32_t* act_pid, uint32_t* act_dist,
+                                              int na, float st, Mid mid = Mid()) {
+    const int lane = lane_id();
+    const int g = lane >> 3, j = lane & 7;
+    const uint32_t fs = ix.f.fstride;
+    const uint32_t moff = fs - 16u;                                       // the 16-B piece that ends with the metadata
+    const int mc = (int)(moff >> 7), mj = (int)((moff & 127u) >> 4);
+    for (int base = 0; base < na; base += 8 * FR) {
+        uint4 p[FR][NCH];
+#pragma unroll
+        for (int r = 0; r < FR; r++) {
+            const int k = base + 8 * r + g;
+            const uint8_t* row = ix.f.rows + (size_t)act_pid[k < na ? k : 0] * fs + 16u * (uint32_t)j;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                p[r][c] = make_uint4(0u, 0u, 0u, 0u);
+                if (k < na && 128u * (uint32_t)c + 16u * (uint32_t)j < fs) p[r][c] = *reinterpret_cast<const uint4*>(row + 128u * (uint32_t)c);
+            }
+        }
+        if (base == 0) mid();
+#pragma unroll
+        for (int r = 0; r < FR; r++) {
+            uint32_t ah = 0u, al = 0u, ep = 0u, su = 0u;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                ah = udot4(fq.h[c].x, p[r][c].x, ah); al = udot4(fq.l[c].x, p[r][c].x, al);
+                ah = udot4(fq.h[c].y, p[r][c].y, ah); al = udot4(fq.l[c].y, p[r][c].y, al);
+                ah = udot4(fq.h[c].z, p[r][c].z, ah); al = udot4(fq.l[c].z, p[r][c].z, al);
+                ah = udot4(fq.h[c].w, p[r][c].w, ah); al = udot4(fq.l[c].w, p[r][c].w, al);
+                if (c == mc && j == mj) { ep = p[r][c].z; su = p[r][c].w; }   // (the query's bytes are zero there)
+            }
+            ah = group_sum_u32(ah);
+            al = group_sum_u32(al);
+            ep = group_sum_u32(ep);                                       // one lane holds it, the others add 0
+            su = group_sum_u32(su);
+            const int k = base + 8 * r + g;
+            if (k < na && j == 0) {
+                // I = sum (Q - 256 u)^2 = sum Q^2 - 512 sum Q u + 65536 sum u^2, exact
+                const uint64_t A = ((uint64_t)ah << 8) + (uint64_t)al;
+                const uint64_t I = fq.sq + ((uint64_t)su << 16) - (A << 9);
+                const float dh = (float)I * ix.f.dscale;                  // |q^ - p^|^2
+                const float t = (st + (__uint_as_float(ep) + fq.eq)) * ix.f.up;
+                act_dist[k] = dh > t * t ? kAbandoned : 0u;               // (NaN anywhere: not rejected)
+            }
+        }
+    }
+}
+
+// The distance pass of one expansion with the filter in front: the compact rows of all `na` new ids first (the caller's `mid` —
+// its visited-set inserts — runs while they are in flight), then the f32 rows of the ids that were not rejected, through the
+// walk's ordinary pass.  act_dist[k] ends up as the canonical distance bits of id k, or kAbandoned — above every key of a full
+// `nearest`, so `push` turns it down exactly as it would have turned down the distance itself (core/lib.rs:712-714).
+// thr_bits = 0xFFFFFFFF (nearest not full yet, or a build descent: its distance log needs every distance): no filter.
+template <int NB, int RS, int TAIL, int WALK, class Mid = NoMid>
+__device__ __forceinline__ void dist_pass_filtered(const IndexView& ix, const float* q, const FilterQ<filt_chunks<NB, RS, TAIL>()>& fq,
+                                                   uint32_t* act_pid, uint32_t* act_dist, int na, Mid mid, uint32_t thr_bits) {
+    if constexpr (walk_filter(WALK)) {
+        if (fq.on && thr_bits != 0xFFFFFFFFu && na > 0) {
+            constexpr int NCH = filt_chunks<NB, RS, TAIL>();
+            const int lane = lane_id();
+            const float thr = __uint_as_float(thr_bits);
+            const float st = ix.metric ? thr : __builtin_sqrtf(thr);
+            filter_rounds<NCH, filt_rounds<NCH, WALK>()>(ix, fq, act_pid, act_dist, na, st, mid);
+            wave_sync();
+            const bool in = lane < na;
+            const uint32_t pid = in ? act_pid[lane] : 0u;
+            const bool keep = in && act_dist[lane] != kAbandoned;
+            const uint64_t km = __ballot(keep);
+            const int pos = __popcll(km & ((1ull << lane) - 1ull));
+            wave_sync();
+            if (keep) act_pid[pos] = pid;                                  // slot order is kept
+            wave_sync();
+            const int ns = __popcll(km);
+            fq.seen += (uint32_t)na;
+            fq.rejected += (uint32_t)(na - ns);
+            if (ns) dist_rounds_walk<NB, RS, TAIL, WALK>(ix, q, act_pid, act_dist, ns);
+            wave_sync();
+            const uint32_t d = keep ? act_dist[pos] : kAbandoned;
+            wave_sync();
+            if (in) act_dist[lane] = d;
+            return;
+        }
+    }
+    dist_rounds_walk<NB, RS, TAIL, WALK>(ix, q, act_pid, act_dist, na, mid, thr_bits);
 }
 
 // ---------------------------------------------------------------------------
@@ -1531,7 +1757,8 @@ template <int NB, int RS, int TAIL, int LAT = 0>
 __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t* rows, int row_stride, int links,
                                              const float* q, WState& st, Visited& vis, uint32_t* act_pid,
                                              uint32_t* act_dist, Counters& ctr, bool is_zero, DistLog& dlog,
-                                             QuadLead* quad = nullptr) {
+                                             QuadLead* quad = nullptr,
+                                             const FilterQ<filt_chunks<NB, RS, TAIL>()>& fq = FilterQ<filt_chunks<NB, RS, TAIL>()>()) {
     const int lane = lane_id();
     uint32_t guard = 0;
     const bool row_lane = lane < row_stride && lane < links;
@@ -1637,6 +1864,9 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             const bool sure = ok_nb && stt == kQRoom, maybe = ok_nb && stt == kQFull;
             if constexpr (kSpec) { if (__ballot(maybe)) sq_off = true; }
             const uint64_t sm = __ballot(sure);
+            // reject filter: the furthest distance of a full `nearest` as this expansion begins (`nearest` only improves during it)
+            [[maybe_unused]] uint32_t thr_bits = 0xFFFFFFFFu;
+            if constexpr (walk_filter(LAT)) { if (st.ef > 0 && st.plen >= st.ef && !dlog.log) thr_bits = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32); }
             wave_sync();
             if (sm) {
                 const int my = __popcll(sm & ((1ull << lane) - 1ull));
@@ -1649,7 +1879,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                     }
                 };
                 if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, *quad, act_pid, act_dist, __popcll(sm), mid);
-                else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, __popcll(sm), mid);
+                else dist_pass_filtered<NB, RS, TAIL, LAT>(ix, q, fq, act_pid, act_dist, __popcll(sm), mid, thr_bits);
                 wave_sync();
                 if (sure) my_d = act_dist[my];
             }
@@ -1662,7 +1892,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 if (late) act_pid[my] = nb_pid;
                 wave_sync();
                 if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, *quad, act_pid, act_dist, __popcll(lm));
-                else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, __popcll(lm));
+                else dist_pass_filtered<NB, RS, TAIL, LAT>(ix, q, fq, act_pid, act_dist, __popcll(lm), NoMid(), thr_bits);
                 wave_sync();
                 if (late) my_d = act_dist[my];
             }
@@ -1690,9 +1920,9 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 auto mid = [&]() { if (defer && fresh) tab_idx = tab_insert(vis, nb_pid); };
                 // early abandon (measurement builds): the furthest distance of a full `nearest` as this expansion begins
                 [[maybe_unused]] uint32_t thr_bits = 0xFFFFFFFFu;
-                if constexpr (walk_ea(LAT) > 0) { if (st.plen >= st.ef && !dlog.log) thr_bits = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32); }
+                if constexpr (walk_ea(LAT) > 0 || walk_filter(LAT)) { if (st.ef > 0 && st.plen >= st.ef && !dlog.log) thr_bits = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32); }
                 if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, *quad, act_pid, act_dist, na, mid);
-                else dist_rounds_walk<NB, RS, TAIL, LAT>(ix, q, act_pid, act_dist, na, mid, thr_bits);     // :709-710
+                else dist_pass_filtered<NB, RS, TAIL, LAT>(ix, q, fq, act_pid, act_dist, na, mid, thr_bits);     // :709-710
                 wave_sync();
                 if (fresh) my_d = act_dist[my];
             }

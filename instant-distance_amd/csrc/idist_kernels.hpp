@@ -24,6 +24,53 @@ __global__ void permute_rows_kernel(const float* __restrict__ in, float* __restr
     }
 }
 
+// The compact copy of the point rows behind the walk's reject filter (FilterView, idist_device.hpp): one wave per row.
+// u_k = round((p_k - lo) / step) clamped to [0, 255] for the stored positions that hold a coordinate (padding: 0), in the f32 row's
+// own element order; the row ends with {|p - p^|_2 rounded UP as f32, sum u_k^2}.  A row with a non-finite coordinate gets +inf there:
+// the filter never rejects it.
+__global__ __launch_bounds__(64) void filter_rows_kernel(const float* __restrict__ points, uint32_t n, uint32_t dim, uint32_t stride,
+                                                        uint32_t nb, uint8_t* __restrict__ rows, uint32_t fstride, float lo, float step256) {
+    const int lane = lane_id();
+    const float inv = 1.0f / (256.0f * step256);
+    const double step = 256.0 * (double)step256;
+    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const float* src = points + (size_t)r * stride;
+        uint8_t* dst = rows + (size_t)r * fstride;
+        double e2 = 0.0;
+        uint32_t su = 0;
+        bool bad = false;
+        for (uint32_t pos = (uint32_t)lane; pos < fstride - 8u; pos += 64u) {
+            uint32_t u = 0;
+            if (pos < stride && natural_pos(pos, nb) < dim) {
+                const float p = src[pos];
+                if (__builtin_fabsf(p) <= 3.0e38f) {
+                    u = (uint32_t)__builtin_fminf(__builtin_fmaxf(__builtin_rintf((p - lo) * inv), 0.0f), 255.0f);
+                    const double e = (double)p - ((double)lo + (double)u * step);
+                    e2 += e * e;
+                    su += u * u;
+                } else {
+                    bad = true;
+                }
+            }
+            dst[pos] = (uint8_t)u;
+        }
+        for (int m = 1; m < 64; m <<= 1) {
+            const unsigned long long b = __builtin_bit_cast(unsigned long long, e2);
+            const uint32_t blo = (uint32_t)__shfl_xor((int)(uint32_t)b, m, 64), bhi = (uint32_t)__shfl_xor((int)(uint32_t)(b >> 32), m, 64);
+            e2 += __builtin_bit_cast(double, ((unsigned long long)bhi << 32) | blo);
+            su += (uint32_t)__shfl_xor((int)su, m, 64);
+        }
+        const bool any_bad = __ballot(bad) != 0ull;
+        if (lane == 0) {
+            float ep = (float)(__builtin_sqrt(e2) * (1.0 + 1e-6));
+            ep = __uint_as_float(__float_as_uint(ep) + 1u);                // one more ulp up: the cast rounded to nearest
+            if (any_bad) ep = __uint_as_float(0x7f800000u);
+            reinterpret_cast<uint32_t*>(dst + fstride - 8u)[0] = __float_as_uint(ep);
+            reinterpret_cast<uint32_t*>(dst + fstride - 8u)[1] = su;
+        }
+    }
+}
+
 // UpperNode::from_zero for a whole layer, core/lib.rs:323-328, core/types.rs:66-70
 __global__ void snapshot_kernel(const uint32_t* __restrict__ zero, uint32_t* __restrict__ upper_rows, uint32_t rows) {
     const size_t total = (size_t)rows * kM;
@@ -95,14 +142,16 @@ struct Smem {
     uint32_t* dirty;     // dirty-block bitmap of the visited set (graph walks only), dirty_words dwords
     uint32_t* bloom;     // kBloomWords / kBloomLatWords, last in the carve-up (graph walks only)
 };
+// quad_ctl = false: a single-wave search kernel has no use for the four-wave walk's hand-over block (1 KB: at ef_search 100 it is the
+// difference between seven and eight resident walks per CU with a 16-KB visited set)
 __host__ __device__ inline size_t smem_bytes(uint32_t stride, uint32_t wcap, bool build, uint32_t bloom_words = kBloomWords,
-                                             uint32_t dirty_words = 0) {
+                                             uint32_t dirty_words = 0, bool quad_ctl = true) {
     wcap = (wcap + 1u) & ~1u;   // keeps everything behind W 16-B aligned
-    size_t b = (size_t)stride * 4 + (size_t)wcap * 8 + 2 * 64 * 4 + sizeof(QuadCtl) + (size_t)(bloom_words + dirty_words) * 4;
+    size_t b = (size_t)stride * 4 + (size_t)wcap * 8 + 2 * 64 * 4 + (quad_ctl ? sizeof(QuadCtl) : 0) + (size_t)(bloom_words + dirty_words) * 4;
     if (build) b += (size_t)(3 * 64 + 8) * 8;
     return b;
 }
-__device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t wcap, bool build, uint32_t dirty_words = 0) {
+__device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t wcap, bool build, uint32_t dirty_words = 0, bool quad_ctl = true) {
     Smem s;
     s.q = reinterpret_cast<float*>(base);
     base += (size_t)stride * 4;
@@ -113,7 +162,7 @@ __device__ __forceinline__ Smem carve(uint8_t* base, uint32_t stride, uint32_t w
     s.act_pid = reinterpret_cast<uint32_t*>(base);
     s.act_dist = s.act_pid + 64;
     s.ctl = reinterpret_cast<QuadCtl*>(s.act_dist + 64);
-    s.dirty = s.act_dist + 64 + sizeof(QuadCtl) / 4;
+    s.dirty = s.act_dist + 64 + (quad_ctl ? sizeof(QuadCtl) / 4 : 0);
     s.bloom = s.dirty + dirty_words;
     return s;
 }
@@ -146,6 +195,7 @@ struct SearchArgs {
     uint32_t* done_host;
     uint32_t* done_count;
     uint32_t done_seq;
+    unsigned long long* filt_counts;   // [2] device words of the context: candidates the reject filter examined / rejected
 };
 // the LDS tail region (after the dirty-block bitmap) holds the Bloom filter or the on-chip visited set
 __device__ __forceinline__ void visited_attach_tab(Visited& v, uint32_t* mem, uint32_t log2_entries) {
@@ -185,7 +235,7 @@ __device__ __forceinline__ void visited_attach_q16(Visited& v, uint32_t log2_ent
 template <int NB, int RS, int TAIL, int LAT = 0>
 __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) void search_kernel(IndexView ix, SearchArgs a) {
     IDIST_DYN_SMEM(smem_raw);
-    const Smem sm = carve(smem_raw, ix.stride, a.wcap, false, a.vis.dirty_words);
+    const Smem sm = carve(smem_raw, ix.stride, a.wcap, false, a.vis.dirty_words, !walk_thin(LAT));
     const int lane = lane_id();
     const uint32_t slot = blockIdx.x;
     Visited vis{a.visited + (size_t)slot * a.vis.slot_words, ix.n, sm.dirty, a.vis.shift, a.vis.dirty_words,
@@ -223,6 +273,10 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         for (uint32_t e = lane; e < ix.dim; e += 64) sm.q[blocked_pos(e, nb)] = qsrc[e];
         wave_sync();
 
+        // the query on the reject filter's lattice (walks compiled with it): registers, for the whole walk
+        FilterQ<filt_chunks<NB, RS, TAIL>()> fq;
+        if constexpr (walk_filter(LAT)) filter_stage_query(ix, sm.q, fq);
+
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
         if (a.tie_spill) { st.spill = a.tie_spill + (size_t)slot * a.tie_spill_cap; st.spill_cap = a.tie_spill_cap; }
         Counters ctr{0, 0, 0};
@@ -233,11 +287,11 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
             const bool is_zero = cur == 0;
             st.ef = is_zero ? (int)a.ef : 1;                           // :366-371
             if (is_zero) {
-                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true, nolog, &ql);
+                search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, kM2, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, true, nolog, &ql, fq);
                 break;
             }
             const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false, nolog, &ql);
+            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, kM, sm.q, st, vis, sm.act_pid, sm.act_dist, ctr, false, nolog, &ql, fq);
             w_cull(st);                                                // :377-379
             visited_clear(vis);
             visited_begin(vis, (uint32_t)st.plen);
@@ -267,6 +321,12 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         }
         status |= st.status;
         visited_clear(vis);                                            // leave the slot empty for its next search
+        if constexpr (walk_filter(LAT)) {                               // what the reject filter did for this query (idist_search_ctx_filter_counts)
+            if (lane == 0 && fq.seen) {
+                atomicAdd(&a.filt_counts[0], (unsigned long long)fq.seen);
+                atomicAdd(&a.filt_counts[1], (unsigned long long)fq.rejected);
+            }
+        }
     }
     if constexpr (walk_quad(LAT)) quad_release_helpers(ql);
     if (lane == 0 && status) {

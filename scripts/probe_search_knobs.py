@@ -34,10 +34,15 @@ for ef in [int(x) for x in os.environ.get("PB_EFS", "600,800").split(",")]:
         os.environ.update(env)
         r = bench.Runner(job, ida, h, d_q)          # a fresh context samples the knobs
         outs = r.alloc_out(ef)
-        for _ in range(4):
+        r.run(outs)
+        torch.cuda.synchronize()
+        r.search.filter_counts()                    # what the reject filter examined / rejected: reset
+        for _ in range(3):
             r.run(outs)
         torch.cuda.synchronize()
         r.search.check_status()
+        seen, rej = r.search.filter_counts()
+        row[nm + "_filter_rejected_share"] = round(rej / seen, 4) if seen else None
         row[nm + "_ms"] = round(float(r.search.kernel_times_ms(3).min()), 3)
         row[nm + "_checksum"] = int(outs[0].to(torch.int64).sum().item())
         for k in env:

@@ -1,0 +1,101 @@
+"""The walk's reject filter (FilterView / filter_rounds in csrc/idist_device.hpp): `Search::push` (core/lib.rs:704-720) needs the
+distance of a candidate only when it accepts it (`Err(idx) if idx < ef`); the others need a PROOF that their canonical distance
+exceeds nearest[ef-1]'s, which a one-byte-per-coordinate copy of the row can give.  Whatever the filter does, ids, order, counts,
+distance bits and the work counters {n_dist, n_exp0, n_expU} must be the oracle's — and the filter must actually be at work
+(idist_search_ctx_filter_counts says what it looked at and what it rejected)."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from engines import engine_params
+
+ON_CHIP = {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip"}          # wide on-chip walk whatever the index size (test-build knobs)
+WALKS = (("two thin waves per SIMD (the default of a filtered wide walk)", dict(ON_CHIP)),
+         ("thin, tiny quotient set: ids overflow to the bitmap (second pass)", {**ON_CHIP, "IDIST_TAB_LOG2": "7"}),
+         ("fat wave, id set", {**ON_CHIP, "IDIST_TAB_FORMAT": "ids"}),
+         ("fat wave, quotient set", {**ON_CHIP, "IDIST_TAB_FORMAT": "q16", "IDIST_FILTER_WAVES": "1"}),
+         ("two 256-register waves per SIMD (long-walk form)", {**ON_CHIP, "IDIST_TAB_FORMAT": "q16", "IDIST_W2_EF": "0", "IDIST_FILTER_WAVES": "1"}),
+         ("classic", {"IDIST_WALK": "classic", "IDIST_VISITED": "onchip"}))
+
+
+@pytest.fixture(params=engine_params())
+def eng(request, engine_loader):
+    return engine_loader(request.param), request.param
+
+
+def S(kind, emu, gpu):
+    return emu if kind == "emu" else gpu
+
+
+def _data(rng, kind_, n, dim):
+    if kind_ == "outliers":              # a few coordinates far outside the lattice: clamped, their error is in the row's record
+        a = pc.gen_points(rng, n, dim, "lowrank")
+        rows = rng.choice(n, size=max(2, n // 25), replace=False)
+        a[rows, rng.integers(0, dim, size=len(rows))] *= np.float32(40.0)
+        return a
+    if kind_ == "offset":                # data far from the origin: the padding coordinates (zeros) must not count
+        return (pc.gen_points(rng, n, dim, "uniform") + np.float32(7.0)).astype(np.float32)
+    if kind_ == "constant":              # degenerate range
+        return np.full((n, dim), 0.5, dtype=np.float32)
+    return pc.gen_points(rng, n, dim, kind_)
+
+
+@pytest.mark.parametrize("dim,kind_,metric", [(128, "lowrank", 0), (300, "lowrank", 0), (300, "uniform", 1), (16, "uniform", 0),
+                                              (100, "lowrank", 1), (7, "grid", 0), (48, "outliers", 0), (33, "offset", 0),
+                                              (768, "lowrank", 0), (5, "constant", 0), (124, "lowrank", 0)])
+def test_filter_changes_nothing_and_rejects(eng, oracle, monkeypatch, dim, kind_, metric):
+    ida, kind = eng
+    if kind == "emu" and dim == 768:
+        pytest.skip("768-d under the emulator: covered on the GPU")
+    pc.use_test_build(monkeypatch)                     # (the walk knobs and the counters exist in the test build only)
+    rng = np.random.default_rng(1000 + dim)
+    n, ef = S(kind, 260, 20000), S(kind, 12, 100)
+    pts = _data(rng, kind_, n, dim)
+    q = _data(rng, kind_, S(kind, 12, 600), dim)
+    q[0] = pts[n // 2]
+    q[1] = pts[1] * np.float32(3.0) + np.float32(11.0)                   # a query far outside the lattice: large |q - q^|, nothing rejected wrongly
+    cfg = oracle.default_config(metric=metric, ef_search=ef, ef_construction=S(kind, 16, 100))
+    oix = oracle.Index.build(pts, cfg, threads=S(kind, 1, 8))
+    want = oix.search(q, threads=S(kind, 1, 8))
+    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().metric(metric).ef_search(ef))
+    total = [0, 0]
+    for name, env in WALKS:
+        for flt in ("1", "0"):
+            with pc.search_variant(env), monkeypatch.context() as m:
+                m.setenv("IDIST_FILTER", flt)
+                srch = ida.Search()
+                got = h.search_batch(q, srch, counters=True)
+                seen, rejected = srch.filter_counts()
+            pc.check_search_result(got, want)
+            if flt == "0":
+                assert seen == 0, name
+            else:
+                total[0] += seen
+                total[1] += rejected
+                assert seen <= int(want.counters[:, 0].sum()) and rejected <= seen
+    filtered = dim <= 496 or dim in (768,)              # compact rows beyond four chunks have no tile without a compile-time geometry
+    if not filtered:
+        assert total[0] == 0
+    elif kind_ == "constant":
+        assert total[1] == 0                            # every distance is 0: nothing can be rejected
+    else:
+        assert total[0] > 0
+        if kind_ in ("lowrank", "uniform", "offset"):
+            assert total[1] > 0.3 * total[0], total     # the filter is at work (the larger GPU cases reject ~90 %)
+
+
+def test_filter_unfiltered_geometry_runs_without(eng, oracle, monkeypatch):
+    """1000-d rows: no compile-time instantiation and more than four chunks per compact row — the walk runs unfiltered."""
+    ida, kind = eng
+    pc.use_test_build(monkeypatch)
+    rng = np.random.default_rng(5)
+    n, dim, ef = S(kind, 120, 4000), 1000, S(kind, 10, 100)
+    pts = pc.gen_points(rng, n, dim, "lowrank")
+    q = pc.gen_points(rng, S(kind, 6, 200), dim, "lowrank")
+    oix = oracle.Index.build(pts, oracle.default_config(ef_search=ef, ef_construction=S(kind, 12, 100)), threads=S(kind, 1, 8))
+    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, ida.Builder().ef_search(ef))
+    with pc.search_variant(WALKS[0][1]):
+        srch = ida.Search()
+        got = h.search_batch(q, srch, counters=True)
+        assert srch.filter_counts() == (0, 0)
+    pc.check_search_result(got, oix.search(q))

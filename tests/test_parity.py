@@ -228,7 +228,9 @@ def test_build_batched_is_schedule_independent(eng, oracle, monkeypatch):
     envs = [{}, {"IDIST_BUILD_CHUNK": "5"}, {"IDIST_BUILD_NO_FAST": "1"}, {"IDIST_LATENCY_NQ": "0"}, {"IDIST_BUILD_QUAD": "0"},
             {"IDIST_LATENCY_NQ": "0", "IDIST_WALK": "classic"}]
     if kind == "gpu":
-        envs += [{"IDIST_BUILD_CHUNK": "1"}, {"IDIST_BUILD_CHUNK": "16"}, {"IDIST_LATENCY_NQ": "4000000000"}]
+        # (IDIST_BUILD_STREAMS=off: ONE descent stream with one queue head / visited region — the sequential steps of the growth phase
+        #  must then stay on it, run_build's `seq1`)
+        envs += [{"IDIST_BUILD_CHUNK": "1"}, {"IDIST_BUILD_CHUNK": "16"}, {"IDIST_LATENCY_NQ": "4000000000"}, {"IDIST_BUILD_STREAMS": "off"}]
     else:
         # which kernel selects for the new points (Gram matrix on MFMA / LDS tile), whether step B finds its distances in
         # the published log, how early the descents' visited set spills: none of it may show in the graph
@@ -685,3 +687,87 @@ def test_strict_ties_spill_to_hbm(eng, oracle, monkeypatch):
     h2 = ida.Hnsw.from_parts(pts2, o2.zero, o2.layers, ida.Builder().ef_search(S(kind, 20, 100)).tie_capacity(2))
     q2 = pts2[: S(kind, 6, 100)] + np.float32(0.5)
     pc.check_search_result(h2.search_batch(q2, ida.Search(), counters=True), o2.search(q2))
+
+
+def test_concurrent_build_on_the_tie_bags(eng, oracle, monkeypatch):
+    """A CONCURRENT (pipelined) build whose strict ties live in the HBM bags has one descent stream's worth of queue heads,
+    visited bitmaps and bags: the sequential steps that open a layer must not run beside the next step's descents on them
+    (run_build's `seq1`; round-5 advisor finding).  The graph must be the one the same schedule gives with a tie region large
+    enough to need no bag — ties are handled bit-identically either way (core/lib.rs:564: the heap is unbounded) — and the two
+    zero-layer copies of the pipeline must agree (IDIST_BUILD_CHECK)."""
+    ida, kind = eng
+    pc.use_test_build(monkeypatch)                     # (IDIST_TIE_SPILL / IDIST_BUILD_CHECK exist in the test build only)
+    rng = np.random.default_rng(29)
+    n, ef = S(kind, 330, 9000), S(kind, 12, 60)
+    pts = pc.gen_points(rng, n, 3, "grid")             # 216 distinct integer points: duplicates and mass ties
+    base = lambda: ida.Builder().metric(1).ef_search(ef).ef_construction(ef).max_batch(S(kind, 8, 0))   # noqa: E731
+    monkeypatch.setenv("IDIST_BUILD_CHECK", "1")
+    ref = ida.Hnsw.from_ordered_points(pts, base().tie_capacity(4096))
+    zr, lr = ref.into_parts()
+    monkeypatch.setenv("IDIST_TIE_SPILL", "1")
+    for _ in range(S(kind, 1, 3)):                      # (a race would not show every time)
+        hb = ida.Hnsw.from_ordered_points(pts, base().tie_capacity(1))
+        assert hb.info().tie_capacity == 1 and hb.build_stats().tie_overflow == 0     # no growth: the bags took the ties
+        zero, layers = hb.into_parts()
+        assert np.array_equal(zero, zr) and all(np.array_equal(x, y) for x, y in zip(layers, lr))
+    ida.Hnsw.from_parts(pts, zr, lr, base())           # idist_index_import validates every row
+
+
+def _poison(rng, a, share):
+    """NaN, +inf and -inf coordinates in `share` of the rows each (some rows get two kinds: inf - inf = NaN inside the distance)."""
+    n, dim = a.shape
+    for val in (np.nan, np.inf, -np.inf):
+        rows = rng.choice(n, size=max(1, int(n * share)), replace=False)
+        a[rows, rng.integers(0, dim, size=len(rows))] = val
+    return a
+
+
+def _canon_nan_bits(a):
+    """OrderedFloat: all NaNs are equal (core/types.rs:229-234 via ordered-float) — x86 makes 0xFFC00000 out of inf - inf, the GPU
+    stores its canonical 0x7FC00000; every other value must match bit for bit."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return np.where(np.isnan(a), np.uint32(0x7FC00000), a.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("dim", [5, 12, 300])
+def test_non_finite_coordinates(eng, oracle, dim, metric):
+    """NaN / +inf / -inf coordinates in points and queries.  The reference orders candidates by (OrderedFloat<f32>, PointId)
+    (core/types.rs:229-234): NaN is the GREATEST distance and all NaNs tie (then the pid decides); +inf is an ordinary largest
+    finite-side value.  Search on the oracle's graph (every walk variant) and the exact build must be the oracle's."""
+    ida, kind = eng
+    if kind == "emu" and dim == 300 and metric == 1:
+        pytest.skip("300-d under the emulator once is enough")
+    rng = np.random.default_rng(41 + dim + metric)
+    n = S(kind, 140 if dim == 300 else 220, 2500)
+    pts = _poison(rng, pc.gen_points(rng, n, dim), 0.04)
+    q = _poison(rng, pc.gen_points(rng, S(kind, 10, 64), dim), 0.12)
+    q[0] = pts[3]                                                      # a stored point (finite or not)
+    ef = S(kind, 16, 100)
+    cfg = oracle.default_config(metric=metric, ef_search=ef, ef_construction=S(kind, 20, 100))
+    oix = oracle.Index.build(pts, cfg, threads=1)
+    want = oix.search(q)
+    assert np.isnan(want.dist[want.pid != pc.INVALID]).any()          # the case is live: NaN distances are among the answers
+    b = ida.Builder().metric(metric).ef_search(ef).ef_construction(S(kind, 20, 100)).max_batch(1)
+    h = ida.Hnsw.from_parts(pts, oix.zero, oix.layers, b)
+    for _, lat in pc.pick_variants(pc.SEARCH_VARIANTS, dim + metric, 4):
+        with pc.search_variant(lat):
+            got = h.search_batch(q, ida.Search(), counters=True)
+        assert np.array_equal(got.count, want.count) and np.array_equal(got.pid, want.pid), lat
+        assert np.array_equal(_canon_nan_bits(got.distance), _canon_nan_bits(want.dist)), lat
+        assert np.array_equal(got.counters, want.counters), lat
+    one = h.search_batch(q[:1], ida.Search(), counters=True)          # the scalar call (four waves per query)
+    assert np.array_equal(one.pid, want.pid[:1]) and np.array_equal(one.counters, want.counters[:1])
+    # the distance kernel on its own
+    ids = rng.integers(0, n, size=(len(q), 40)).astype(np.uint32)
+    wd = np.array([[oracle.distance(q[i], pts[j], metric) for j in ids[i]] for i in range(len(q))], dtype=np.float32)
+    assert np.array_equal(_canon_nan_bits(h.distances(q, ids)), _canon_nan_bits(wd))
+    # exact build: select_heuristic's `<` on OrderedFloat (core/lib.rs:676-679) with NaN / inf distances in the candidate sets
+    for _, lat in pc.pick_variants(pc.BUILD_VARIANTS, dim + metric, 2):
+        with pc.search_variant(lat):
+            hb = ida.Hnsw.from_ordered_points(pts, b)
+        zero, layers = hb.into_parts()
+        assert np.array_equal(zero, oix.zero), lat
+        assert all(np.array_equal(x, y) for x, y in zip(layers, oix.layers)), lat
+        st = hb.build_stats()
+        assert (st.n_dist, st.n_exp0, st.n_expU) == (oix.build_counters.n_dist, oix.build_counters.n_exp0, oix.build_counters.n_expU)

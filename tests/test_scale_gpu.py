@@ -182,3 +182,50 @@ def test_growth_phase_quality_on_hard_data_gpu(engine_loader, oracle, monkeypatc
     # select_heuristic gives no connectivity guarantee (a point every neighbour prunes has no in-link: the reference's graphs have
     # such points too on clustered data), so reachability is held against the CPU build's, not against n
     assert reach["g/8"] >= min(reach["cpu threaded"], reach["g/32"]) - n // 200, (reach, recall)
+
+
+@pytest.mark.gpu
+def test_34m_points_beyond_the_quotient_sets_reach_gpu(engine_loader, oracle):
+    """n = 34,000,000 x 4-d: beyond what the 16-bit quotient form of the on-chip visited set can address (33.5 M with the 32-KB
+    set: id-form fallback in the search AND in every build descent), 512-B dirty blocks in the overflow bitmap, point and
+    adjacency row offsets past 2^32 bytes (zero layer 8.7 GB).  The reference's only bound is n < u32::MAX (core/lib.rs:256).
+    Default build on the GPU; the oracle searches the EXPORTED graph (points and zero layer borrowed in place) for 256 queries at
+    ef_search 100 and 300: ids, order, counts, distance bits and work counters must be identical, wide and narrow batches; plus the
+    size-independent properties of the graph on a strided sample of rows."""
+    import time
+
+    ida = engine_loader("gpu")
+    n, dim, nq = 34_000_000, 4, 256
+    rng = np.random.default_rng(34)
+    pts = rng.random((n, dim), dtype=np.float32)
+    q = rng.random((nq, dim), dtype=np.float32)
+    q[:32] = pts[np.linspace(0, n - 1, 32).astype(np.int64)]               # stored points from the whole id range
+    t0 = time.time()
+    h = ida.Hnsw.from_ordered_points(pts, ida.Builder())
+    st = h.build_stats()
+    print(f"34M x 4-d: built in {st.seconds:.1f} s on the device ({time.time() - t0:.1f} s with the upload), {st.n_batches} steps")
+    zero, layers = h.into_parts()
+    sizes = oracle.layer_sizes(n)
+    assert [l.shape[0] for l in layers] == sizes[1:] and zero.shape == (n, 64)
+    rows = zero[:: 17]                                                       # 2M rows from the whole range
+    valid = rows != pc.INVALID
+    assert np.all(valid[:, :-1] >= valid[:, 1:]) and np.all(rows[valid] < n) and np.all(valid[:, 0])
+    assert not np.any(rows == (np.arange(0, n, 17, dtype=np.uint32)[:, None]))
+    assert np.all(zero[-1000:][zero[-1000:] != pc.INVALID] < n)              # the last rows: offsets beyond 8.7e9 bytes
+    oix = oracle.Index.from_arrays(pts, zero, layers, oracle.default_config(), borrow=True)
+    for ef in (100, 300):
+        h.set_ef_search(ef)
+        oix.set_ef_search(ef)
+        want = oix.search(q, threads=16)
+        s = ida.Search()
+        got = h.search_batch(q, s, counters=True)                            # wide batch
+        pc.check_search_result(got, want)
+        again = h.search_batch(q, s, counters=True)                          # the same Search again: the visited set was cleared
+        pc.check_search_result(again, want)
+        narrow = h.search_batch(q[:8], ida.Search(), counters=True)          # four waves per query
+        assert np.array_equal(narrow.pid, want.pid[:8]) and np.array_equal(narrow.counters, want.counters[:8])
+        assert np.array_equal(pc.bits(narrow.distance), pc.bits(want.dist[:8]))
+        assert np.all(got.count == ef) and np.all(got.distance[:, :-1] <= got.distance[:, 1:])
+        assert np.all(got.distance[:32, 0] == 0)                             # stored points find themselves (or an exact duplicate)
+    truth, _ = h.bruteforce(q[:64], 10)
+    assert pc.recall_at(got.pid[:64], truth, 10) > 0.9
