@@ -111,7 +111,7 @@ def effective_cores():
     return cores
 
 
-def measure_traffic(args, n, dim, nq, ef):
+def measure_traffic(args, n, dim, nq, ef, mix=None):
     """roofline.traffic, measured in this session: two child passes of THIS command under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE cannot share a pass: TCC has four counter slots; PMC passes serialise kernels, so they cannot run inside the
     timed process).  FETCH_SIZE is corrected with a factor calibrated IN THE SAME PASS on the same access pattern with a known
@@ -136,6 +136,7 @@ def measure_traffic(args, n, dim, nq, ef):
             if r.returncode != 0:
                 return None, f"{ctr} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
             known = [int(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("known_read_bytes_per_launch")]
+            known_c = [int(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("known_compact_read_bytes_per_launch")]
             dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
             if not dbs:
                 return None, f"{ctr} pass left no results database"
@@ -143,10 +144,12 @@ def measure_traffic(args, n, dim, nq, ef):
             rows = cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (ctr,)).fetchall()
             sk = [v for k, v in rows if "search_kernel" in k]
             cal = [v for k, v in rows if "distance_batch_kernel" in k]
+            cal_c = [v for k, v in rows if "filter_bound_kernel" in k]
             if not sk:
                 return None, f"{ctr} pass saw no search_kernel dispatch"
             full = [v for v in sk if v >= 0.5 * max(sk)]                    # the full-batch launches
-            got[ctr] = {"kb": sum(full) / len(full), "launches": len(full), "calib_kb": cal[-1] if cal else None, "known": known[-1] if known else None}
+            got[ctr] = {"kb": sum(full) / len(full), "launches": len(full), "calib_kb": cal[-1] if cal else None, "known": known[-1] if known else None,
+                        "calib_c_kb": cal_c[-1] if cal_c else None, "known_c": known_c[-1] if known_c else None}
         except Exception as e:  # noqa: BLE001
             return None, f"{ctr} pass: {e!r}"[:300]
         finally:
@@ -154,13 +157,25 @@ def measure_traffic(args, n, dim, nq, ef):
     f = got["FETCH_SIZE"]
     if not f["calib_kb"] or not f["known"]:
         return None, "no calibration dispatch in the FETCH_SIZE pass"
-    factor = f["known"] / (f["calib_kb"] * 1024.0)
+    factor_rows = f["known"] / (f["calib_kb"] * 1024.0)
+    factor_compact = f["known_c"] / (f["calib_c_kb"] * 1024.0) if f.get("calib_c_kb") and f.get("known_c") else None
+    # The filtered walk mixes two request patterns, and FETCH_SIZE under-reports them differently (a request is tallied at 64 B
+    # whatever its size): correct the reported bytes with the factor of the kernel's OWN byte mix — its f32 rows and adjacency rows
+    # at the f32-gather factor, its compact rows at theirs (mix = the kernel's counters, rank0_report).
+    factor = factor_rows
+    if mix and factor_compact and mix.get("compact", 0) > 0:
+        total = mix["rows"] + mix["compact"]
+        factor = total / (mix["rows"] / factor_rows + mix["compact"] / factor_compact)
     fetch = f["kb"] * 1024.0 * factor
     write = got["WRITE_SIZE"]["kb"] * 1024.0
     return {"bytes_per_launch": int(fetch + write), "fetch_bytes_reported": int(f["kb"] * 1024), "fetch_correction_factor": round(factor, 4),
+            "fetch_correction_factor_f32_rows": round(factor_rows, 4),
+            "fetch_correction_factor_compact_rows": round(factor_compact, 4) if factor_compact else None,
             "fetch_bytes_corrected": int(fetch), "write_bytes_reported": int(write), "launches_averaged": f["launches"],
-            "calibration": "distance_batch_kernel over a random permutation of all rows of the same index in the same PMC pass: "
-                           f"{f['known']} B known, {int(f['calib_kb'] * 1024)} B reported",
+            "calibration": "distance_batch_kernel / filter_bound_kernel over a random permutation of all rows of the same index in the same "
+                           f"PMC pass: f32 rows {f['known']} B known, {int(f['calib_kb'] * 1024)} B reported"
+                           + (f"; compact rows {f['known_c']} B known, {int(f['calib_c_kb'] * 1024)} B reported; the launch's own byte mix weights the two"
+                              if factor_compact else ""),
             "how": "two child passes of this command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, this box, this session; "
                    "WRITE_SIZE uncalibrated (9 MB of 70 GB); fabric bytes (Infinity-Cache hits included)"}, None
 
@@ -547,6 +562,9 @@ def run_bench(job, args):
         perm = torch.randperm(n, device=job.dev).to(torch.int32).cpu().numpy().astype(np.uint32).reshape(1, n)
         hnsw.distances(d_q[:1].cpu().numpy(), perm)
         print("known_read_bytes_per_launch", n * hnsw.info().row_stride * 4 + n * 4, flush=True)
+        # ... and the same for the compact rows of the reject filter (another request pattern: 320-B rows at C3)
+        hnsw.filter_bounds(d_q[:1].cpu().numpy(), perm)
+        print("known_compact_read_bytes_per_launch", n * ((hnsw.info().row_stride + 8 + 63) // 64 * 64) + n * 4, flush=True)
         for _ in range(2):
             r.run(outs)
         job.sync()
@@ -617,7 +635,8 @@ def rank0_report(job, args, cfgd, ida, r, outs, hnsw, d_pts, build, m):
             continue
     traffic, traffic_why = (None, "skipped (--no-traffic, N > 1, or a 10M-point configuration)")
     if not args.no_traffic and world == 1 and job.cuda and n * dim <= 2_000_000_000:
-        traffic, traffic_why = measure_traffic(args, n, dim, nq, chosen)
+        compact_b = examined * compact_row
+        traffic, traffic_why = measure_traffic(args, n, dim, nq, chosen, mix={"rows": launch_bytes - compact_b, "compact": compact_b})
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic["bytes_per_launch"] if traffic else None,
                 "traffic_over_algorithmic": round(traffic["bytes_per_launch"] / launch_bytes, 4) if traffic else None,
@@ -796,6 +815,13 @@ def rank0_report(job, args, cfgd, ida, r, outs, hnsw, d_pts, build, m):
                       "replication": m["replication"], "replicate_seconds": round(m["t_rep"], 3), **m["rep"]},
            "build": build, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "single_query": single,
            "pcie_inclusive": pcie}
+    try:                                                     # rank 0's footprint (C5: 30.7 GB of points + the index + the oracle's leg)
+        import resource
+        free_b, total_b = torch.cuda.mem_get_info() if job.cuda else (0, 0)
+        out["memory"] = {"host_rss_peak_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0, 2),
+                         "hbm_in_use_at_end_gb": round((total_b - free_b) / 1e9, 2), "hbm_total_gb": round(total_b / 1e9, 1)}
+    except Exception:  # noqa: BLE001
+        pass
     if replica_check is not None:
         out["replica_check"] = replica_check
     if checks is not None:

@@ -297,6 +297,15 @@ idist_status idist_search_batch_sharded(const idist_index* const* replicas, idis
 idist_status idist_distance_batch(const idist_index* idx, const float* queries, uint32_t nq,
                                   const uint32_t* ids, uint32_t n_ids, float* out_dist);
 
+/* The walk's reject filter for id lists, on its own: out[q][i] = a LOWER BOUND of
+ * distance(queries[q], points[ids[q][i]]) in the index's metric, computed from the one-byte-per-coordinate copy of the row
+ * alone with the walk's own loads and arithmetic — `Search::push` (core/lib.rs:704-720) is spared the f32 row of a candidate
+ * whose bound exceeds the furthest distance of a full `nearest`.  0 where there is no bound (IDIST_INVALID ids, rows with a
+ * non-finite coordinate, indexes without the copy).  Host pointers.  tests/ hold the bound against idist_distance_batch;
+ * bench.py uses one pass over all rows as the known byte count its traffic counters are calibrated on. */
+idist_status idist_filter_bound_batch(const idist_index* idx, const float* queries, uint32_t nq,
+                                      const uint32_t* ids, uint32_t n_ids, float* out_bound);
+
 /* Exact k nearest neighbours by exhaustive scan with the canonical distance (the
  * brute-force check of tests/all.rs:60-67); host pointers. */
 idist_status idist_bruteforce(const idist_index* idx, const float* queries, uint32_t nq,

@@ -116,6 +116,7 @@ SYMBOLS = {
     "idist_search_batch_sharded": (C.c_int32, [C.POINTER(_vp), C.POINTER(_vp), C.c_uint32, _f32p, C.c_uint32, _u32p, _f32p,
                                                _u32p, _u32p]),
     "idist_distance_batch": (C.c_int32, [_vp, _f32p, C.c_uint32, _u32p, C.c_uint32, _f32p]),
+    "idist_filter_bound_batch": (C.c_int32, [_vp, _f32p, C.c_uint32, _u32p, C.c_uint32, _f32p]),
     "idist_bruteforce": (C.c_int32, [_vp, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
 }
 

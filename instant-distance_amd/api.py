@@ -362,6 +362,8 @@ class Hnsw:
                            host_points: np.ndarray | None = None) -> "Hnsw":
         """Build from points already resident in HBM (row-major n x dim f32, PointId order)."""
         builder = builder or Builder()
+        if host_points is not None and (tuple(host_points.shape) != (n, dim) or host_points.dtype != np.float32):
+            raise ValueError(f"host_points must be the same {n} x {dim} float32 rows that sit on the device, got {host_points.dtype} {host_points.shape}")
         cfg = builder._config()
         h = C.c_void_p()
         L = _lib()
@@ -508,6 +510,16 @@ class Hnsw:
         out = np.zeros(ids.shape, dtype=np.float32)
         L = _lib()
         L.check(L.idist_distance_batch(self._h, _capi.f32p(q), q.shape[0], _capi.u32p(ids), ids.shape[1], _capi.f32p(out)))
+        return out
+
+    def filter_bounds(self, queries, ids) -> np.ndarray:
+        """The walk's reject filter over id lists: a lower bound of every distance, from the compact copy of the rows alone
+        (0 where there is none) — idist_filter_bound_batch."""
+        q = _as_points(queries)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32).reshape(q.shape[0], -1)
+        out = np.zeros(ids.shape, dtype=np.float32)
+        L = _lib()
+        L.check(L.idist_filter_bound_batch(self._h, _capi.f32p(q), q.shape[0], _capi.u32p(ids), ids.shape[1], _capi.f32p(out)))
         return out
 
     def bruteforce(self, queries, k: int):

@@ -43,8 +43,24 @@ namespace {
 // which kernels run or which graph is built.
 #if defined(IDIST_VARIANTS) || defined(IDIST_PROBE) || defined(IDIST_EMU)
 inline const char* test_env(const char* name) { return getenv(name); }
+inline void warn_ignored_knobs() {}
 #else
 constexpr const char* test_env(const char*) { return nullptr; }
+// The product ignores every other IDIST_* variable: say so once (a script written against the test build would otherwise measure
+// the default behaviour without a hint).  The names are not known here — anything with the prefix that is not one of the three.
+extern "C" char** environ;
+inline void warn_ignored_knobs() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (char** e = environ; e && *e; e++) {
+            if (strncmp(*e, "IDIST_", 6) != 0) continue;
+            const char* eq = strchr(*e, '=');
+            const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+            if (name == "IDIST_COMBINE" || name == "IDIST_SYNC" || name == "IDIST_KERNEL_EVENTS") continue;
+            fprintf(stderr, "libidist: %s is ignored by the product library (test knobs exist in libidist_variants.so only)\n", name.c_str());
+        }
+    });
+}
 #endif
 
 char g_err_anchor;                                       // (its address identifies this loaded library, see index_alloc)
@@ -246,6 +262,7 @@ struct Knobs {
                                       // workgroups per CU, one for 768-d rows; 0 = never)
     static Knobs from_env() {
         Knobs k;
+        warn_ignored_knobs();
         if (const char* e = test_env("IDIST_EA")) k.ea = atoi(e);
         if (const char* e = test_env("IDIST_W2_EF")) k.w2_ef = (uint32_t)strtoul(e, nullptr, 10);
         if (const char* e = test_env("IDIST_LATENCY_NQ")) k.latency_nq = (uint32_t)strtoul(e, nullptr, 10);
@@ -318,12 +335,21 @@ struct idist_search_ctx {
 
 namespace {
 
+// The row geometries the kernels are instantiated for at compile time — ONE list: IDIST_DISPATCH instantiates them, and every
+// policy that asks "is this a runtime-geometry index?" (launch_search, run_build, filter_applies) asks has_template_geometry().
+#define IDIST_GEO_LIST(X, L, CALL) X(L, CALL, 4, 0, 0) /* dim 128 */ X(L, CALL, 9, 1, 1) /* dim 300 */ X(L, CALL, 24, 0, 0) /* dim 768 */
+#define IDIST_GEO_TEST(L, CALL, NB_, RS_, TAIL_) if ((L).nb == (NB_) && (L).rs == (RS_) && (L).tail == (TAIL_)) return true;
+inline bool has_template_geometry(const Layout& L) {
+    IDIST_GEO_LIST(IDIST_GEO_TEST, L, _)
+    return false;
+}
+#define IDIST_GEO_CASE(L, CALL, NB_, RS_, TAIL_) \
+    if (!idist_geo_hit_ && (L).nb == (NB_) && (L).rs == (RS_) && (L).tail == (TAIL_)) { idist_geo_hit_ = true; CALL(NB_, RS_, TAIL_); }
 #define IDIST_DISPATCH(L, CALL)                                         \
     do {                                                                \
-        if ((L).nb == 4 && (L).rs == 0 && (L).tail == 0) { CALL(4, 0, 0); }        /* dim 128 */ \
-        else if ((L).nb == 9 && (L).rs == 1 && (L).tail == 1) { CALL(9, 1, 1); }   /* dim 300 */ \
-        else if ((L).nb == 24 && (L).rs == 0 && (L).tail == 0) { CALL(24, 0, 0); } /* dim 768 */ \
-        else { CALL(-1, -1, -1); }                                      \
+        bool idist_geo_hit_ = false;                                    \
+        IDIST_GEO_LIST(IDIST_GEO_CASE, L, CALL)                         \
+        if (!idist_geo_hit_) { CALL(-1, -1, -1); }                      \
     } while (0)
 
 idist_status index_alloc(uint32_t n, uint32_t dim, const idist_config* cfg, const uint32_t* layer_len,
@@ -458,8 +484,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     const Knobs knobs = Knobs::from_env();
     CHK(variants_check(knobs.classic));
     // no compile-time instantiation of the row geometry (IDIST_DISPATCH): the runtime-geometry kernels
-    const bool rt_geometry = !((ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
-                               (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0));
+    const bool rt_geometry = !has_template_geometry(ix->L);
 
     const uint32_t tie_cap = tie_capacity(cfg);
     const uint32_t wcap = cfg.ef_construction + 64 + tie_cap + 64;
@@ -1068,9 +1093,7 @@ constexpr uint32_t kLongWalkEf = 512u;   // ef_search from which wide on-chip ba
 // Geometries the search kernels have no filter tile for (compact rows beyond four 128-B chunks without a compile-time instantiation)
 // and indexes the copy finds no memory for simply run without it.
 bool filter_applies(const idist_index* ix) {
-    const bool tmpl = (ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
-                      (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0);
-    return ix->n > 0 && (tmpl || filt_stride(ix->L.stride) <= 128u * (uint32_t)kFiltRtChunks);
+    return ix->n > 0 && (has_template_geometry(ix->L) || filt_stride(ix->L.stride) <= 128u * (uint32_t)kFiltRtChunks);
 }
 idist_status filter_ensure(const idist_index* ix) {
     if (ix->filt_state.load(std::memory_order_acquire) != 0) return IDIST_OK;
@@ -1158,8 +1181,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const bool quad = tab_fit && !ctx->knobs.classic && nq <= quad_nq;
     const size_t row_bytes = (size_t)ix->n * ix->L.stride * 4;
     const bool long_rows = ix->L.stride >= 256u;
-    const bool rt_rows = !((ix->L.nb == 4 && ix->L.rs == 0 && ix->L.tail == 0) || (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) ||
-                           (ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0));   // no compile-time instantiation of the row geometry
+    const bool rt_rows = !has_template_geometry(ix->L);   // no compile-time instantiation of the row geometry
     const bool cache_resident = long_rows ? row_bytes < kLongRowOnChipBytes : row_bytes <= kShortRowBitmapBytes;   // "served best by many small waves"
     // With the reject filter in front (round 6) the on-chip walk stays ahead at every ef_search the set fits — 1M x 128 at ef 200 / 400:
     // 8.5 / 15.4 ms against 10.6 / 20.8 ms on the bitmap walk, 4M x 64-d at ef 100 / 200: 5.1 / 10.3 against 5.9 / 11.8 — and the ef
@@ -2155,6 +2177,48 @@ idist_status idist_distance_batch(const idist_index* idx, const float* queries, 
     if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(out_dist, d_out, ib, hipMemcpyDeviceToHost)) != hipSuccess) {
         release();
         return fail(IDIST_ERR_HIP, "distance_batch: %s", hipGetErrorString(e));
+    }
+    release();
+    return IDIST_OK;
+}
+
+idist_status idist_filter_bound_batch(const idist_index* idx, const float* queries, uint32_t nq, const uint32_t* ids,
+                                      uint32_t n_ids, float* out_bound) {
+    if (!idx) return fail(IDIST_ERR_INVALID_ARG, "idx is null");
+    if (nq == 0 || n_ids == 0) return IDIST_OK;
+    if (!queries || !ids || !out_bound) return fail(IDIST_ERR_INVALID_ARG, "null pointer");
+    HIPCHK(hipSetDevice(idx->device));
+    if (filter_applies(idx)) CHK(filter_ensure(idx));
+    const size_t qb = (size_t)nq * idx->dim * 4, ib = (size_t)nq * n_ids * 4;
+    if (idx->filt_state.load(std::memory_order_acquire) != 1) {          // no filter for this index: no bound
+        memset(out_bound, 0, ib);
+        return IDIST_OK;
+    }
+    float *d_q = nullptr, *d_out = nullptr;
+    uint32_t* d_ids = nullptr;
+    auto release = [&]() { hipFree(d_q); hipFree(d_out); hipFree(d_ids); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_q, qb)) != hipSuccess || (e = hipMalloc((void**)&d_out, ib)) != hipSuccess ||
+        (e = hipMalloc((void**)&d_ids, ib)) != hipSuccess ||
+        (e = hipMemcpy(d_q, queries, qb, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_ids, ids, ib, hipMemcpyHostToDevice)) != hipSuccess) {
+        release();
+        return fail(IDIST_ERR_HIP, "filter_bound_batch staging: %s", hipGetErrorString(e));
+    }
+    const uint32_t chunks = (n_ids + 63u) / 64u;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)nq * chunks, 1u << 20);
+    const size_t smem = smem_bytes(idx->L.stride, 0, false);
+    IndexView view = idx->view();
+#define LAUNCH_FB(NB_, RS_, TAIL_)                                                               \
+    {                                                                                             \
+        auto kD = filter_bound_kernel<NB_, RS_, TAIL_>;                                           \
+        IDIST_LAUNCH(kD, grid, 64, smem, (hipStream_t) nullptr, view, d_q, nq, d_ids, n_ids, d_out); \
+    }
+    IDIST_DISPATCH(idx->L, LAUNCH_FB);
+#undef LAUNCH_FB
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipMemcpy(out_bound, d_out, ib, hipMemcpyDeviceToHost)) != hipSuccess) {
+        release();
+        return fail(IDIST_ERR_HIP, "filter_bound_batch: %s", hipGetErrorString(e));
     }
     release();
     return IDIST_OK;

@@ -718,7 +718,9 @@ __device__ __forceinline__ void filter_stage_query(const IndexView& ix, const fl
 // One filter pass over act_pid[0..na): act_dist[k] = kAbandoned where the compact row PROVES that the canonical distance
 // exceeds the threshold (st = sqrt of the furthest distance of a full `nearest` for squared L2, the distance itself for L2),
 // 0 otherwise.  8 lanes per row like the f32 gather; FR rounds of 8 rows are requested before the first is consumed.
-template <int NCH, int FR, class Mid = NoMid>
+// BOUND = true (idist_filter_bound_batch): act_dist[k] = the bits of the largest threshold the row would be rejected against —
+// a lower bound of the canonical distance in the index's metric (st is not used).
+template <int NCH, int FR, class Mid = NoMid, bool BOUND = false>
 __device__ __forceinline__ void filter_rounds(const IndexView& ix, const FilterQ<NCH>& fq, const uint32_t* act_pid, uint32_t* act_dist,
                                               int na, float st, Mid mid = Mid()) {
     const int lane = lane_id();
@@ -760,8 +762,15 @@ __device__ __forceinline__ void filter_rounds(const IndexView& ix, const FilterQ
                 const uint64_t A = ((uint64_t)ah << 8) + (uint64_t)al;
                 const uint64_t I = fq.sq + ((uint64_t)su << 16) - (A << 9);
                 const float dh = (float)I * ix.f.dscale;                  // |q^ - p^|^2
-                const float t = (st + (__uint_as_float(ep) + fq.eq)) * ix.f.up;
-                act_dist[k] = dh > t * t ? kAbandoned : 0u;               // (NaN anywhere: not rejected)
+                if constexpr (BOUND) {
+                    // rejected iff dh > ((st + E) up)^2  <=>  st < sqrt(dh) / up - E: that supremum, rounded down
+                    float b = __builtin_sqrtf(dh) * 0.999999f / ix.f.up - (__uint_as_float(ep) + fq.eq) * 1.000001f;
+                    b = b > 0.0f ? b : 0.0f;                              // (NaN: 0 — no bound)
+                    act_dist[k] = __float_as_uint(ix.metric ? b : b * b * 0.999999f);
+                } else {
+                    const float t = (st + (__uint_as_float(ep) + fq.eq)) * ix.f.up;
+                    act_dist[k] = dh > t * t ? kAbandoned : 0u;           // (NaN anywhere: not rejected)
+                }
             }
         }
     }

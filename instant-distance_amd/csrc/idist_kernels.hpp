@@ -376,6 +376,40 @@ __global__ __launch_bounds__(64) void distance_batch_kernel(IndexView ix, const 
     }
 }
 
+// The reject filter on its own (idist_filter_bound_batch): for id lists, the lower bound of the canonical distance the compact
+// rows give — what the walk's filter compares with nearest[ef-1] — through the walk's own loads and arithmetic (filter_rounds).
+template <int NB, int RS, int TAIL>
+__global__ __launch_bounds__(64) void filter_bound_kernel(IndexView ix, const float* __restrict__ queries, uint32_t nq,
+                                                         const uint32_t* __restrict__ ids, uint32_t n_ids, float* __restrict__ out) {
+    IDIST_DYN_SMEM(smem_raw);
+    const Smem sm = carve(smem_raw, ix.stride, 0, false);
+    const int lane = lane_id();
+    const uint32_t chunks = (n_ids + 63u) / 64u;
+    const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
+    constexpr int NCH = filt_chunks<NB, RS, TAIL>();
+    for (uint32_t w = blockIdx.x; w < nq * chunks; w += gridDim.x) {
+        const uint32_t qi = w / chunks, c0 = (w % chunks) * 64u;
+        wave_sync();
+        for (uint32_t o = lane; o < ix.stride; o += 64) sm.q[o] = 0.0f;
+        wave_sync();
+        for (uint32_t e = lane; e < ix.dim; e += 64) sm.q[blocked_pos(e, nb)] = queries[(size_t)qi * ix.dim + e];
+        wave_sync();
+        FilterQ<NCH> fq;
+        filter_stage_query(ix, sm.q, fq);
+        const uint32_t i = c0 + lane;
+        uint32_t id = kInvalid;
+        if (i < n_ids) id = ids[(size_t)qi * n_ids + i];
+        const bool ok = fq.on && id != kInvalid && id < ix.n;
+        const uint64_t m = __ballot(ok);
+        const int my = __popcll(m & ((1ull << lane) - 1ull));
+        if (ok) sm.act_pid[my] = id;
+        wave_sync();
+        if (m) filter_rounds<NCH, 2, NoMid, true>(ix, fq, sm.act_pid, sm.act_dist, __popcll(m), 0.0f);
+        wave_sync();
+        if (i < n_ids) out[(size_t)qi * n_ids + i] = ok ? __uint_as_float(sm.act_dist[my]) : 0.0f;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Exhaustive exact top-k with the canonical distance (ground truth; the brute
 // force of tests/all.rs:60-67).  One wave per query, W machinery with ef = k.

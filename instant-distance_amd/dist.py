@@ -81,7 +81,9 @@ def replicate_index(hnsw: Hnsw | None, builder: Builder, src: int = 0, chunk_byt
     if rank == src:
         info = hnsw.info()
         meta[0], meta[1], meta[2], meta[3] = info.n, info.dim, info.n_upper, info.ef_search
-        meta[4] = 1 if (hnsw.points.shape[1] == info.dim or info.n == 0) else 0     # does the source hold a host copy of the points?
+        # does the source hold a host copy of the points (all n rows, f32)?  The host transport broadcasts it as it is.
+        hp = hnsw.points
+        meta[4] = 1 if (info.n == 0 or (tuple(hp.shape) == (info.n, info.dim) and hp.dtype == np.float32)) else 0
         meta[8:8 + info.n_upper] = list(info.layer_len)[: info.n_upper]
     meta = _bcast_meta(meta, src)
     n, dim, n_upper, ef = int(meta[0]), int(meta[1]), int(meta[2]), int(meta[3])

@@ -99,3 +99,40 @@ def test_filter_unfiltered_geometry_runs_without(eng, oracle, monkeypatch):
         got = h.search_batch(q, srch, counters=True)
         assert srch.filter_counts() == (0, 0)
     pc.check_search_result(got, oix.search(q))
+
+
+@pytest.mark.parametrize("dim,kind_,metric", [(300, "lowrank", 0), (128, "uniform", 1), (16, "uniform", 0), (48, "outliers", 0),
+                                              (33, "offset", 1), (7, "grid", 0), (768, "lowrank", 0), (100, "nonfinite", 0)])
+def test_filter_bound_never_exceeds_the_canonical_distance(eng, oracle, dim, kind_, metric):
+    """idist_filter_bound_batch: what the walk's filter compares with nearest[ef-1], for arbitrary (query, point) pairs.  The bound
+    must never exceed the canonical distance of idist_distance_batch (= FloatArray::distance, py/lib.rs:378-421; the oracle's on a
+    sample) — for queries from the data's distribution, far outside the lattice, and with non-finite coordinates — and on ordinary
+    data it must be tight enough to be of use."""
+    ida, kind = eng
+    if kind == "emu" and dim == 768:
+        pytest.skip("768-d under the emulator: covered on the GPU")
+    rng = np.random.default_rng(77 + dim)
+    n, nq, n_ids = S(kind, 300, 20000), S(kind, 6, 64), S(kind, 70, 2000)
+    base = "lowrank" if kind_ == "nonfinite" else kind_
+    pts = _data(rng, base, n, dim)
+    q = _data(rng, base, nq, dim)
+    q[1] = q[1] * np.float32(5.0) - np.float32(3.0)                       # far outside the lattice
+    if kind_ == "nonfinite":
+        pts[rng.choice(n, 6, replace=False), rng.integers(0, dim, 6)] = [np.nan, np.inf, -np.inf, np.nan, np.inf, -np.inf]
+        q[2, 3], q[3, 0] = np.nan, np.inf
+    zero = np.full((n, 64), pc.INVALID, dtype=np.uint32)
+    h = ida.Hnsw.from_parts(pts, zero, [], ida.Builder().metric(metric))    # an empty graph is enough for both gather kernels
+    ids = rng.integers(0, n, size=(nq, n_ids)).astype(np.uint32)
+    ids[0, 1] = pc.INVALID
+    ids[2, :4] = [0, 1, 2, 3]
+    bound = h.filter_bounds(q, ids)
+    dist = h.distances(q, ids)
+    d0 = np.array([oracle.distance(q[0], pts[j], metric) if j != pc.INVALID else np.inf for j in ids[0]], dtype=np.float32)
+    assert np.array_equal(pc.bits(dist[0]), pc.bits(d0))
+    assert np.all(np.isfinite(bound)) and np.all(bound >= 0)
+    ok = ~np.isnan(dist)                                                    # NaN distances sort last: any bound is below them
+    assert np.all(bound[ok] <= dist[ok]), float(np.max(bound[ok] - dist[ok]))
+    assert bound[0, 1] == 0
+    if kind_ in ("lowrank", "uniform", "offset"):
+        body = bound[4:] / np.maximum(dist[4:], np.float32(1e-30))          # queries from the data's own distribution
+        assert np.median(body) > (0.5 if dim < 64 else 0.8), float(np.median(body))
