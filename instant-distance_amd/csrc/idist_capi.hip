@@ -465,6 +465,9 @@ idist_status device_status_to_code(uint32_t st, int32_t tie_policy) {
 }
 
 // ---- build driver: the per-layer insertion schedule of Hnsw::new, core/lib.rs:304-329 ----
+bool filter_applies(const idist_index* ix);
+idist_status filter_ensure(const idist_index* ix);
+
 idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     const uint32_t n = ix->n;
     if (prog) { prog->total = n; prog->slot[0] = n ? 1 : 0; prog->slot[1] = 0; }   // pid 0 is in from the start
@@ -704,7 +707,22 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     BCHK(hipEventCreate(&e0));
     BCHK(hipEventCreate(&e1));
 
+    // Round 6: the descents of concurrent steps run with the reject filter in front of their distance passes (§4.5) — the compact
+    // copy of the rows is made now (every row is in place before the first insertion), the log takes bound-form entries for the
+    // candidates the filter turned down, step B resolves them (dlog_resolve).  IDIST_BUILD_FILTER=0 (test knob): without.
+    // Rows of at least 256 floats: C3 1.20 -> 1.03 s, 1M x 768 2.82 -> 2.35 s, 1M x 384 1.71 -> 1.29 s; 128-d rows lose (a 192-B compact
+    // row saves little of a 512-B one and their fat unfiltered descents are faster: 1M x 128 0.70 -> 0.85 s, C2 0.107 -> 0.118 s) and
+    // keep the unfiltered descents (profiles/probe_r06g_build_filter_c3.jsonl, probe_r06h_build_filter_dims.jsonl; same graphs).
+    // IDIST_BUILD_FILTER=1 (test knob) forces it for every geometry the filter applies to.
+    const char* bf_env = test_env("IDIST_BUILD_FILTER");
+    bool build_filter = cfg.has_heuristic && !ext && tab16 && knobs.filter && filter_applies(ix) &&
+                        (bf_env ? bf_env[0] != '0' : ix->L.stride >= 256u);
+    if (build_filter) {
+        CHK(filter_ensure(ix));
+        build_filter = ix->filt_state.load(std::memory_order_acquire) == 1;
+    }
     IndexView view = ix->view();
+    if (!build_filter) view.f = FilterView{};
     BuildArgs a{};
     a.top = top;
     a.efc = cfg.ef_construction;
@@ -849,6 +867,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         /* narrow steps (the growth phase of a layer, max_batch = 1): four waves per insertion, like narrow search batches */ \
         auto kAq16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, true, true)>; \
         auto kAo16w2 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
+        /* ... and with the reject filter in front of the distance passes (thin: one f32 round in flight, query fragment from LDS) */ \
+        auto kAf = build_insert_kernel<NB_, RS_, TAIL_, walk_thin_filter(2)>;                      \
         auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
@@ -858,6 +878,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         if (ext) { IDIST_LAUNCH(kX, 1, 64, smemX, sA, viewA, aA, d_ext_work, ext_cap); }           \
         IDIST_VARIANT_BUILD(NB_, RS_, TAIL_)                                                       \
         else if (tab16 && a_quad && B <= quad_B) { IDIST_LAUNCH(kAq16, std::min(B, slots), 256, smem, sA, viewA, aA); } \
+        else if (tab16 && build_filter) { IDIST_LAUNCH(kAf, gridA, 64, smem, sA, viewA, aA); }     \
         else if (tab16 && a_regs256) { IDIST_LAUNCH(kAo16w2, gridA, 64, smem, sA, viewA, aA); }    \
         else if (tab16) { IDIST_LAUNCH(kAo16, gridA, 64, smem, sA, viewA, aA); }                   \
         else { IDIST_LAUNCH(kAo, gridA, 64, smem, sA, viewA, aA); }                                \

@@ -1357,6 +1357,19 @@ __device__ __forceinline__ bool visited_insert(const Visited& v, uint32_t pid, i
 // overflow bitmap are not logged: a miss is always legal, the caller recomputes.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kDlogMiss = 0xFFFFFFFFu;            // never a canonical distance pattern
+// Descents with the reject filter (round 6): a candidate the filter turned down has no distance to log — what is known is that it
+// lies BEYOND the threshold of that expansion (d > thr, strictly: the furthest distance of a full `nearest`, which is at least the
+// descent's final one).  It is logged in bound form, the sign bit (free: canonical distance patterns are non-negative or the
+// positive canonical NaN) over the threshold's bits; step B resolves it against the one comparand it needs (dlog_resolve).
+constexpr uint32_t kDlogBound = 0x80000000u;
+__device__ __forceinline__ bool dlog_is_bound(uint32_t v) { return (v & kDlogBound) != 0u && v != kDlogMiss; }
+// `v` will be compared as `d < x` (strict, core/lib.rs:678): a bound-form entry with thr >= x decides it (d > thr >= x: false) and is
+// replaced by thr itself — any value >= x gives the same verdict; one with thr < x decides nothing: a miss, the caller recomputes.
+__device__ __forceinline__ uint32_t dlog_resolve(uint32_t v, uint32_t x) {
+    if (!dlog_is_bound(v)) return v;
+    const uint32_t thr = v & ~kDlogBound;
+    return thr >= x ? thr : kDlogMiss;
+}
 struct DistLog {
     uint64_t* log;      // HBM [ids the set holds]: dist_bits << 32 | index in the set; nullptr = nothing is logged
     uint32_t n;         // entries (wave-uniform)
@@ -1817,6 +1830,11 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         bool fresh = false;
         int na = 0, tab_idx = -1;
         uint32_t my_d = 0, my_id = nb_pid;
+        // reject filter: the furthest distance of a full `nearest` as this expansion begins (`nearest` only improves during it)
+        [[maybe_unused]] uint32_t thr_bits = 0xFFFFFFFFu;
+        if constexpr (walk_ea(LAT) > 0 || walk_filter(LAT)) {
+            if (st.ef > 0 && st.plen >= st.ef && (walk_filter(LAT) || !dlog.log)) thr_bits = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32);
+        }
         if (is_nb && nb_pid >= ix.n) st.status |= kStBadRow;
         const bool ok_nb = is_nb && nb_pid < ix.n;
 
@@ -1873,9 +1891,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
             const bool sure = ok_nb && stt == kQRoom, maybe = ok_nb && stt == kQFull;
             if constexpr (kSpec) { if (__ballot(maybe)) sq_off = true; }
             const uint64_t sm = __ballot(sure);
-            // reject filter: the furthest distance of a full `nearest` as this expansion begins (`nearest` only improves during it)
-            [[maybe_unused]] uint32_t thr_bits = 0xFFFFFFFFu;
-            if constexpr (walk_filter(LAT)) { if (st.ef > 0 && st.plen >= st.ef && !dlog.log) thr_bits = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32); }
             wave_sync();
             if (sm) {
                 const int my = __popcll(sm & ((1ull << lane) - 1ull));
@@ -1928,8 +1943,6 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 wave_sync();
                 auto mid = [&]() { if (defer && fresh) tab_idx = tab_insert(vis, nb_pid); };
                 // early abandon (measurement builds): the furthest distance of a full `nearest` as this expansion begins
-                [[maybe_unused]] uint32_t thr_bits = 0xFFFFFFFFu;
-                if constexpr (walk_ea(LAT) > 0 || walk_filter(LAT)) { if (st.ef > 0 && st.plen >= st.ef && !dlog.log) thr_bits = (uint32_t)((st.W[st.ef - 1] & kKeyMask) >> 32); }
                 if constexpr (walk_quad(LAT)) quad_dist_pass<NB, RS, TAIL>(ix, q, *quad, act_pid, act_dist, na, mid);
                 else dist_pass_filtered<NB, RS, TAIL, LAT>(ix, q, fq, act_pid, act_dist, na, mid, thr_bits);     // :709-710
                 wave_sync();
@@ -1987,7 +2000,12 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
         if (na) {                                                                       // Search::push in slot order, :606-608
             ctr.n_dist += (uint32_t)na;
             if (fresh) key = ((uint64_t)my_d << 32) | my_id;
-            if (dlog.log) dlog_append(dlog, fresh ? tab_idx : -1, my_d);
+            if (dlog.log) {
+                // (a candidate the filter turned down is logged in bound form: beyond this expansion's threshold)
+                uint32_t log_d = my_d;
+                if constexpr (walk_filter(LAT)) { if (my_d == kAbandoned) log_d = kDlogBound | thr_bits; }
+                dlog_append(dlog, fresh ? tab_idx : -1, log_d);
+            }
             w_push_keys<push_chunks<LAT>()>(st, key, fresh);
         }
         w_truncate(st);                                    // :612

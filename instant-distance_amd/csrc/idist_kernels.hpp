@@ -558,6 +558,9 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
     for (uint32_t o = lane * 4; o < ix.stride; o += 256)
         *reinterpret_cast<float4*>(sm.q + o) = *reinterpret_cast<const float4*>(prow + o);
     wave_sync();
+    // the new point on the reject filter's lattice (descents compiled with it, §4.5)
+    FilterQ<filt_chunks<NB, RS, TAIL>()> fq;
+    if constexpr (walk_filter(LAT)) filter_stage_query(ix, sm.q, fq);
     // search.reset(), :443: the visited set was emptied when the slot's previous descent ended
     push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, dl);  // :444
     const int num = a.layer == 0 ? kM2 : kM;                      // :445
@@ -565,7 +568,7 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
         st.ef = cur <= (int)a.layer ? (int)a.efc : 1;             // :448-452
         if (cur > (int)a.layer) {                                 // :453-457
             const uint32_t* rows = ix.upper + (size_t)ix.layer_off[cur - 1] * kM;
-            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dl, ql);
+            search_layer<NB, RS, TAIL, LAT>(ix, rows, kM, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, false, dl, ql, fq);
             w_cull(st);
             visited_clear(vis);
             visited_begin(vis, (uint32_t)st.plen);
@@ -580,7 +583,7 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
                     dlog_append(dl, on ? vis_index(vis, (uint32_t)k) : -1, (uint32_t)(k >> 32));
                 }
         } else {                                                  // :458-461
-            search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dl, ql);
+            search_layer<NB, RS, TAIL, LAT>(ix, ix.zero, kM2, num, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, a.layer == 0, dl, ql, fq);
             break;
         }
     }
@@ -1134,6 +1137,9 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
             const bool selL = lane < ns0, discL = lane >= ns0 && lane < ncur;
             const uint64_t below = (1ull << lane) - 1ull;
             uint32_t dn = selL ? dn_spec : kDlogMiss;        // d(new, selected entry of this lane), requested before the inbox walk
+            // (an entry the descent's reject filter turned down is there in bound form: it decides `d(new, s) < x` for the one x this
+            //  lane compares with — d(new, pid) in front of the new point, d(pid, s) behind it — or counts as a miss)
+            dn = dlog_resolve(dn, (lane < ncur && key < knew) ? cd_new : curd);
             const bool miss = selL && dn == kDlogMiss;
             const uint64_t mm = __ballot(miss);
 #ifdef IDIST_PROBE
@@ -1237,6 +1243,7 @@ __global__ __launch_bounds__(64) void build_update_fast_kernel(IndexView ix, Bui
                 const uint32_t a_pid = (uint32_t)news[ai];
                 uint32_t dv = kDlogMiss;
                 if (lane < ns0 && a.use_dlog) dv = build_dlog_find(a, a_pid, X[lane]);
+                if (dlog_is_bound(dv)) dv = kDlogMiss;      // (bound form, §4.5: this path compares a column with several values — recompute)
                 if (lane < ns0) Dn[ai * kFastX + lane] = dv;
                 int nmiss = 0;
                 // columns [0, ns0) that missed + the other new points: gather those rows

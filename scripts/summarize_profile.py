@@ -17,7 +17,7 @@ except OSError:
     res["commit"] = None
 KEYS = ("search_kernel", "build_insert_kernel", "build_select_mfma_kernel", "copy_rows_kernel", "build_select_kernel", "build_update_fast_kernel", "build_update_simple_kernel", "build_update_kernel",
         "bruteforce_kernel", "distance_batch_kernel", "mfma_dist_kernel", "rerank_kernel", "kth_threshold_kernel",
-        "row_norms_kernel", "permute_rows_kernel", "snapshot_kernel", "validate_rows_kernel")
+        "row_norms_kernel", "permute_rows_kernel", "snapshot_kernel", "validate_rows_kernel", "filter_rows_kernel", "filter_bound_kernel")
 
 
 def short(name):

@@ -40,7 +40,9 @@ SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by
 # (the third field: the variant runs every selection in the reference's own order, so its count of distance calls inside
 #  select_heuristic / add_neighbor_heuristic must equal the oracle's n_heur)
 BUILD_VARIANTS = (("on-chip (narrow steps: four waves per insertion)", {}),
-                  ("on-chip, one wave per insertion also in narrow steps", {"IDIST_BUILD_QUAD": "0"}),
+                  ("on-chip, one wave per insertion also in narrow steps (descents with the reject filter where the policy has it: rows >= 256 floats)", {"IDIST_BUILD_QUAD": "0"}),
+                  ("on-chip, one wave per insertion, descents WITH the reject filter at every row length", {"IDIST_BUILD_QUAD": "0", "IDIST_BUILD_FILTER": "1"}),
+                  ("on-chip, one wave per insertion, descents WITHOUT the reject filter", {"IDIST_BUILD_QUAD": "0", "IDIST_BUILD_FILTER": "0"}),
                   ("on-chip, 512-register descent waves", {"IDIST_BUILD_QUAD": "0", "IDIST_BUILD_A_REGS": "512"}),
                   ("reference-order kernels: LDS-tile selection, every update from scratch", {"IDIST_BUILD_A2": "tile", "IDIST_BUILD_NO_FAST": "1"}),
                   ("step A2 with the LDS-tile kernel instead of the Gram matrix on MFMA", {"IDIST_BUILD_A2": "tile"}),
@@ -117,7 +119,7 @@ def search_variant(env):
             swapped = None
     keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ", "IDIST_BUILD_A2",
             "IDIST_TAB_FORMAT", "IDIST_BUILD_NO_FAST", "IDIST_BUILD_QUAD", "IDIST_BUILD_A_REGS", "IDIST_W2_EF", "IDIST_FILTER",
-            "IDIST_FILTER_WAVES")
+            "IDIST_FILTER_WAVES", "IDIST_BUILD_FILTER")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)

@@ -225,7 +225,10 @@ def test_build_batched_is_schedule_independent(eng, oracle, monkeypatch):
     pts = pc.gen_points(rng, S(kind, 150, 60000), S(kind, 6, 48), "lowrank" if kind == "gpu" else "uniform")
     b = ida.Builder().max_batch(S(kind, 16, 0))
     ref = None
+    # (IDIST_BUILD_FILTER=0: descents without the reject filter — every distance in the log instead of bound-form entries)
     envs = [{}, {"IDIST_BUILD_CHUNK": "5"}, {"IDIST_BUILD_NO_FAST": "1"}, {"IDIST_LATENCY_NQ": "0"}, {"IDIST_BUILD_QUAD": "0"},
+            {"IDIST_BUILD_FILTER": "0"}, {"IDIST_BUILD_QUAD": "0", "IDIST_BUILD_FILTER": "0"}, {"IDIST_BUILD_FILTER": "1"},
+            {"IDIST_BUILD_QUAD": "0", "IDIST_BUILD_FILTER": "1"},
             {"IDIST_LATENCY_NQ": "0", "IDIST_WALK": "classic"}]
     if kind == "gpu":
         # (IDIST_BUILD_STREAMS=off: ONE descent stream with one queue head / visited region — the sequential steps of the growth phase
