@@ -361,11 +361,20 @@ def phase_build(job, ida, builder, n, dim):
     # Bytes the build's algorithm moves AS EXECUTED HERE: the descents (B_q with ef_construction on the partial
     # graph), every point row fetched for select_heuristic / the neighbour re-selections (n_heur_rows; pairwise
     # reuse is on chip, memoised verdicts fetch nothing), and the adjacency rows read + rewritten.
-    ab = int(st.n_dist * 4 * dim + st.n_exp0 * 256 + st.n_expU * 128 + st.n_heur_rows * 4 * dim
-             + st.n_updates * 512 + n * 256)
+    # Round 6: the descents of rows >= 256 floats look a candidate up in the compact copy of its row first and fetch
+    # the f32 row only of those the filter does not turn down: `examined` compact rows + (n_dist - rejected) f32 rows.
+    rest = int(st.n_exp0 * 256 + st.n_expU * 128 + st.n_heur_rows * 4 * dim + st.n_updates * 512 + n * 256)
+    survey_ab = int(st.n_dist * 4 * dim) + rest
+    ab = int((st.n_dist - st.n_filter_rejected) * 4 * dim + st.n_filter_examined * st.filter_row_bytes) + rest
+    build["reject_filter"] = {"examined": int(st.n_filter_examined), "rejected": int(st.n_filter_rejected),
+                              "rejected_share": round(st.n_filter_rejected / st.n_filter_examined, 4) if st.n_filter_examined else None,
+                              "compact_row_bytes": int(st.filter_row_bytes)}
     build["roofline"] = {"bound": "hbm", "achieved": round(ab / secs / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ab / secs / 1e9 / HBM_PEAK_GBPS, 4), "alg_bytes": ab,
-                         "note": "all build kernels together over the build's device time; per-kernel PMC bytes: profiles/"}
+                         "alg_bytes_one_f32_row_per_push": survey_ab, "frac_one_f32_row_per_push": round(survey_ab / secs / 1e9 / HBM_PEAK_GBPS, 4),
+                         "note": "all build kernels together over the build's device time; bytes the kernels request by their own counters "
+                                 "(descents: f32 rows of the candidates the reject filter did not turn down + compact rows of those it examined); "
+                                 "per-kernel PMC bytes: profiles/"}
     return hnsw, d_pts, build
 
 

@@ -142,6 +142,9 @@ typedef struct idist_build_stats {
                                (early-exit `any`, core/lib.rs:676-679; the pushes of :626-629) — available (non-zero) only when
                                the whole build ran through the reference-order kernels: max_batch = 1 with
                                IDIST_BUILD_A2=tile IDIST_BUILD_NO_FAST=1, or extend_candidates; tests compare it with the oracle */
+    uint64_t n_filter_examined; /* descent pushes (of n_dist) the reject filter looked up in the compact copy of the rows first ... */
+    uint64_t n_filter_rejected; /* ... and of those, the candidates whose f32 row was never fetched (0 / 0: unfiltered descents) */
+    uint64_t filter_row_bytes;  /* bytes of one compact row (0: unfiltered descents): what an examined candidate costs instead of 4 * dim */
 } idist_build_stats;
 
 /* ---- library ------------------------------------------------------------ */

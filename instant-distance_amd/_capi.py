@@ -72,6 +72,7 @@ class BuildStats(C.Structure):
         ("n_sel_pairs", C.c_uint64), ("n_heur_rows", C.c_uint64), ("n_updates", C.c_uint64),
         ("n_updates_fast", C.c_uint64), ("n_updates_full", C.c_uint64),
         ("n_batches", C.c_uint64), ("seconds", C.c_double), ("tie_overflow", C.c_uint64), ("n_heur_ref", C.c_uint64),
+        ("n_filter_examined", C.c_uint64), ("n_filter_rejected", C.c_uint64), ("filter_row_bytes", C.c_uint64),
     ]
 
 

@@ -570,7 +570,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     uint32_t* d_dlog_pd = nullptr;
     uint32_t* d_wcount = nullptr;
     uint32_t *d_row_nsel = nullptr, *d_slow = nullptr, *d_nbr_aux = nullptr;
-    unsigned long long* d_stats = nullptr; // [16]
+    unsigned long long* d_stats = nullptr; // [32]
     const size_t n_edges = (size_t)cap * IDIST_M2;
     const size_t n_touch = std::min<size_t>(n_edges, n);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -702,8 +702,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     BCHK(hipMalloc((void**)&d_touched, nib * n_touch * 4));
     BCHK(hipMalloc((void**)&d_small, 256));
     BCHK(hipMemset(d_small, 0, 256));
-    BCHK(hipMalloc((void**)&d_stats, 128));
-    BCHK(hipMemset(d_stats, 0, 128));
+    BCHK(hipMalloc((void**)&d_stats, 256));
+    BCHK(hipMemset(d_stats, 0, 256));
     BCHK(hipEventCreate(&e0));
     BCHK(hipEventCreate(&e1));
 
@@ -955,9 +955,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     float ms = 0;
     BCHK(hipEventElapsedTime(&ms, e0, e1));
     uint32_t small[8] = {0};
-    unsigned long long stats[16] = {0};
+    unsigned long long stats[32] = {0};
     BCHK(hipMemcpy(&small[6], d_status, 4, hipMemcpyDeviceToHost));
-    BCHK(hipMemcpy(stats, d_stats, 128, hipMemcpyDeviceToHost));
+    BCHK(hipMemcpy(stats, d_stats, 256, hipMemcpyDeviceToHost));
 #undef BCHK
     release();
     ix->stats.n_dist = stats[0];
@@ -970,6 +970,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     ix->stats.seconds = ms * 1e-3;
     ix->stats.n_updates_fast = stats[6];
     ix->stats.n_updates_full = stats[7];
+    ix->stats.n_filter_examined = stats[16];
+    ix->stats.n_filter_rejected = stats[17];
+    ix->stats.filter_row_bytes = build_filter ? filt_stride(ix->L.stride) : 0u;
     // the reference's own count exists only where every selection ran in the reference's order
     ix->stats.n_heur_ref = (ext || (cfg.has_heuristic && no_fast && !a2_mfma && cap == 1)) ? stats[8] : 0;
     if (prog) { prog->slot[0] = n; prog->slot[1] = 0; }

@@ -1490,6 +1490,7 @@ __device__ __forceinline__ uint32_t dlog_find_q16(const uint32_t* PD, uint32_t u
 
 struct Counters {
     uint32_t n_dist, n_exp0, n_expU;
+    uint32_t f_seen = 0, f_rej = 0;   // build descents: what the reject filter examined / turned down (idist_build_stats)
 };
 
 // ---------------------------------------------------------------------------

@@ -511,7 +511,7 @@ struct BuildArgs {
     uint64_t* tie_spill;        // [slots][tie_spill_cap] or null: HBM bags for the ties beyond that capacity (WState::spill)
     uint32_t tie_spill_cap;
     uint32_t* queue;            // work queue heads: [0] step A, [1] step B, [3] step B2, [4] step A2 ([2] = n_slow)
-    unsigned long long* stats;  // [16] n_dist n_exp0 n_expU n_sel_pairs n_heur_rows n_updates n_fast n_full n_heur_ref
+    unsigned long long* stats;  // [32] n_dist n_exp0 n_expU n_sel_pairs n_heur_rows n_updates n_fast n_full n_heur_ref, [9..15] probe build, [16] [17] reject filter: examined, rejected
     uint32_t* status;
 };
 
@@ -587,6 +587,7 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
             break;
         }
     }
+    if constexpr (walk_filter(LAT)) { tot.f_seen += fq.seen; tot.f_rej += fq.rejected; }
 }
 
 // Walk codes with the quad bit (narrow steps: the growth phase of a layer, max_batch = 1) run four-wave workgroups like the
@@ -659,6 +660,10 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
             atomicAdd(&a.stats[0], (unsigned long long)tot.n_dist);
             atomicAdd(&a.stats[1], (unsigned long long)tot.n_exp0);
             atomicAdd(&a.stats[2], (unsigned long long)tot.n_expU);
+        }
+        if (tot.f_seen) {
+            atomicAdd(&a.stats[16], (unsigned long long)tot.f_seen);
+            atomicAdd(&a.stats[17], (unsigned long long)tot.f_rej);
         }
     }
 }
