@@ -650,14 +650,6 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_udot4(a, b, c, false);        // v_dot4_u32_u8
 #endif
 }
-// sum over the 8 lanes of a group, valid in lane j == 0 (the fold's moves: row_shl:4, quad_perm [2,3,0,1], [1,0,3,2])
-__device__ __forceinline__ uint32_t group_sum_u32(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
-    return v;
-}
-
 // A query on the filter's lattice, held in registers for the whole walk: lane j of every 8-lane group keeps the bytes of the
 // positions its loads of a compact row cover (chunk c: positions 128 c + 16 j ... + 15) — the 16-bit coordinate Q split into a
 // high and a low byte plane, so that sum Q u = 256 (h . u) + (l . u) is two v_dot4_u32_u8 per dword of row.
@@ -666,7 +658,7 @@ struct FilterQ {
     uint4 h[NCH], l[NCH];
     float eq = 0.0f;        // |q - q^|_2, rounded up (NaN for a query with a NaN coordinate: nothing is ever rejected)
     uint64_t sq = 0;        // sum Q^2
-    bool on = false;
+    mutable bool on = false; // (a walk switches its own filter off when it is not paying, dist_pass_filtered)
     mutable uint32_t seen = 0, rejected = 0;   // per walk; search_kernel adds them to the context's counters when the query ends
 };
 template <int NCH>
@@ -717,17 +709,25 @@ __device__ __forceinline__ void filter_stage_query(const IndexView& ix, const fl
 
 // One filter pass over act_pid[0..na): act_dist[k] = kAbandoned where the compact row PROVES that the canonical distance
 // exceeds the threshold (st = sqrt of the furthest distance of a full `nearest` for squared L2, the distance itself for L2),
-// 0 otherwise.  8 lanes per row like the f32 gather; FR rounds of 8 rows are requested before the first is consumed.
+// 0 otherwise.  8 lanes per row like the f32 gather; FR (<= 8) rounds of 8 rows are requested before the first is consumed.
+// The dot products of a round are summed over the row's 8 lanes into ALL of them (three DPP adds), and lane j of a group keeps
+// round j's: the integer arithmetic that follows runs ONCE per batch with every lane finishing another row — the row whose 8
+// bytes of metadata that lane fetched itself — instead of once per round with one lane in eight at work.
 // BOUND = true (idist_filter_bound_batch): act_dist[k] = the bits of the largest threshold the row would be rejected against —
 // a lower bound of the canonical distance in the index's metric (st is not used).
+__device__ __forceinline__ uint32_t group_total_u32(uint32_t v) {           // sum over the 8 lanes of a group, in every lane
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad's sum
+    return v;
+}
 template <int NCH, int FR, class Mid = NoMid, bool BOUND = false>
 __device__ __forceinline__ void filter_rounds(const IndexView& ix, const FilterQ<NCH>& fq, const uint32_t* act_pid, uint32_t* act_dist,
                                               int na, float st, Mid mid = Mid()) {
+    static_assert(FR >= 1 && FR <= 8, "lane j of a group finishes round j");
     const int lane = lane_id();
     const int g = lane >> 3, j = lane & 7;
     const uint32_t fs = ix.f.fstride;
-    const uint32_t moff = fs - 16u;                                       // the 16-B piece that ends with the metadata
-    const int mc = (int)(moff >> 7), mj = (int)((moff & 127u) >> 4);
     for (int base = 0; base < na; base += 8 * FR) {
         uint4 p[FR][NCH];
 #pragma unroll
@@ -740,37 +740,45 @@ __device__ __forceinline__ void filter_rounds(const IndexView& ix, const FilterQ
                 if (k < na && 128u * (uint32_t)c + 16u * (uint32_t)j < fs) p[r][c] = *reinterpret_cast<const uint4*>(row + 128u * (uint32_t)c);
             }
         }
+        // the row this lane finishes: round j of the batch, its metadata {|p - p^| (f32 bits), sum u^2} sits in the row's last 8 bytes
+        const int kf = base + 8 * j + g;
+        const bool fin = j < FR && kf < na;
+        uint32_t ep = 0u, su = 0u;
+        if (fin) {
+            const uint32_t* m = reinterpret_cast<const uint32_t*>(ix.f.rows + (size_t)act_pid[kf] * fs + (fs - 8u));
+            ep = m[0];
+            su = m[1];
+        }
         if (base == 0) mid();
+        uint32_t ah_f = 0u, al_f = 0u;
 #pragma unroll
         for (int r = 0; r < FR; r++) {
-            uint32_t ah = 0u, al = 0u, ep = 0u, su = 0u;
+            uint32_t ah = 0u, al = 0u;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
+            for (int c = 0; c < NCH; c++) {                               // (the query's bytes are zero over the padding and the metadata)
                 ah = udot4(fq.h[c].x, p[r][c].x, ah); al = udot4(fq.l[c].x, p[r][c].x, al);
                 ah = udot4(fq.h[c].y, p[r][c].y, ah); al = udot4(fq.l[c].y, p[r][c].y, al);
                 ah = udot4(fq.h[c].z, p[r][c].z, ah); al = udot4(fq.l[c].z, p[r][c].z, al);
                 ah = udot4(fq.h[c].w, p[r][c].w, ah); al = udot4(fq.l[c].w, p[r][c].w, al);
-                if (c == mc && j == mj) { ep = p[r][c].z; su = p[r][c].w; }   // (the query's bytes are zero there)
             }
-            ah = group_sum_u32(ah);
-            al = group_sum_u32(al);
-            ep = group_sum_u32(ep);                                       // one lane holds it, the others add 0
-            su = group_sum_u32(su);
-            const int k = base + 8 * r + g;
-            if (k < na && j == 0) {
-                // I = sum (Q - 256 u)^2 = sum Q^2 - 512 sum Q u + 65536 sum u^2, exact
-                const uint64_t A = ((uint64_t)ah << 8) + (uint64_t)al;
-                const uint64_t I = fq.sq + ((uint64_t)su << 16) - (A << 9);
-                const float dh = (float)I * ix.f.dscale;                  // |q^ - p^|^2
-                if constexpr (BOUND) {
-                    // rejected iff dh > ((st + E) up)^2  <=>  st < sqrt(dh) / up - E: that supremum, rounded down
-                    float b = __builtin_sqrtf(dh) * 0.999999f / ix.f.up - (__uint_as_float(ep) + fq.eq) * 1.000001f;
-                    b = b > 0.0f ? b : 0.0f;                              // (NaN: 0 — no bound)
-                    act_dist[k] = __float_as_uint(ix.metric ? b : b * b * 0.999999f);
-                } else {
-                    const float t = (st + (__uint_as_float(ep) + fq.eq)) * ix.f.up;
-                    act_dist[k] = dh > t * t ? kAbandoned : 0u;           // (NaN anywhere: not rejected)
-                }
+            ah = group_total_u32(ah);
+            al = group_total_u32(al);
+            ah_f = j == r ? ah : ah_f;
+            al_f = j == r ? al : al_f;
+        }
+        if (fin) {
+            // I = sum (Q - 256 u)^2 = sum Q^2 - 512 sum Q u + 65536 sum u^2, exact
+            const uint64_t A = ((uint64_t)ah_f << 8) + (uint64_t)al_f;
+            const uint64_t I = fq.sq + ((uint64_t)su << 16) - (A << 9);
+            const float dh = (float)I * ix.f.dscale;                      // |q^ - p^|^2
+            if constexpr (BOUND) {
+                // rejected iff dh > ((st + E) up)^2  <=>  st < sqrt(dh) / up - E: that supremum, rounded down
+                float b = __builtin_sqrtf(dh) * 0.999999f / ix.f.up - (__uint_as_float(ep) + fq.eq) * 1.000001f;
+                b = b > 0.0f ? b : 0.0f;                                  // (NaN: 0 — no bound)
+                act_dist[kf] = __float_as_uint(ix.metric ? b : b * b * 0.999999f);
+            } else {
+                const float t = (st + (__uint_as_float(ep) + fq.eq)) * ix.f.up;
+                act_dist[kf] = dh > t * t ? kAbandoned : 0u;              // (NaN anywhere: not rejected)
             }
         }
     }
@@ -803,6 +811,10 @@ __device__ __forceinline__ void dist_pass_filtered(const IndexView& ix, const fl
             const int ns = __popcll(km);
             fq.seen += (uint32_t)na;
             fq.rejected += (uint32_t)(na - ns);
+            // A lattice that fits the data badly (heavy tails: most of a row's error in a few clamped coordinates) rejects little and
+            // costs every candidate a second round trip: a walk that has examined 1024 candidates and spared fewer than a quarter of
+            // their f32 rows goes on without the filter.  (Wave-uniform, a function of the query and the index only: deterministic.)
+            if (fq.seen >= 1024u && fq.rejected * 4u < fq.seen) fq.on = false;
             if (ns) dist_rounds_walk<NB, RS, TAIL, WALK>(ix, q, act_pid, act_dist, ns);
             wave_sync();
             const uint32_t d = keep ? act_dist[pos] : kAbandoned;

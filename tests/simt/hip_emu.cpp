@@ -153,7 +153,9 @@ void launch(uint32_t grid, uint32_t block, size_t smem_bytes, const std::functio
                             } else if (ctrl >= 0x111u && ctrl <= 0x11Fu) {                                        // row_shr:n
                                 const uint32_t n = ctrl & 15u;
                                 if ((li & 15u) >= n) src = li - n;
-                            } else { fprintf(stderr, "[hip_emu] dpp ctrl 0x%x not emulated\n", ctrl); abort(); }
+                            } else if (ctrl == 0x140u) src = (int64_t)((li & ~15u) + (15u - (li & 15u)));         // row_mirror
+                            else if (ctrl == 0x141u) src = (int64_t)((li & ~7u) + (7u - (li & 7u)));              // row_half_mirror
+                            else { fprintf(stderr, "[hip_emu] dpp ctrl 0x%x not emulated\n", ctrl); abort(); }
                             if (src < 0 || lo + (uint32_t)src >= hi || !s.lanes[lo + (uint32_t)src].alive) l.res = 1ull << 32;
                             else l.res = (uint32_t)s.lanes[lo + (uint32_t)src].val;
                             break;

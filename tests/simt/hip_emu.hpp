@@ -114,7 +114,7 @@ static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) {
     return (uint32_t)::emu::collective(::emu::OP_READFIRST, v, 0);
 }
 static inline void __threadfence_block() {}
-// v_mov_b32_dpp: quad_perm (ctrl 0x00-0xFF) and row_shl:n / row_shr:n (0x101-0x10F / 0x111-0x11F), all rows and
+// v_mov_b32_dpp: quad_perm (ctrl 0x00-0xFF), row_shl:n / row_shr:n (0x101-0x10F / 0x111-0x11F), row_mirror / row_half_mirror (0x140 / 0x141), all rows and
 // banks enabled; a source lane outside the row reads 0 with bound_ctrl, keeps `old` without.
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     if (row_mask != 0xF || bank_mask != 0xF) { fprintf(stderr, "[hip_emu] dpp row/bank masks not emulated\n"); abort(); }

@@ -35,6 +35,8 @@ def _data(rng, kind_, n, dim):
         return a
     if kind_ == "offset":                # data far from the origin: the padding coordinates (zeros) must not count
         return (pc.gen_points(rng, n, dim, "uniform") + np.float32(7.0)).astype(np.float32)
+    if kind_ == "heavytail":             # Cauchy coordinates: the lattice covers the bulk, every row has clamped outliers -> the filter
+        return rng.standard_cauchy((n, dim)).astype(np.float32)   # rejects little and a walk switches it off for itself
     if kind_ == "constant":              # degenerate range
         return np.full((n, dim), 0.5, dtype=np.float32)
     return pc.gen_points(rng, n, dim, kind_)
@@ -42,7 +44,7 @@ def _data(rng, kind_, n, dim):
 
 @pytest.mark.parametrize("dim,kind_,metric", [(128, "lowrank", 0), (300, "lowrank", 0), (300, "uniform", 1), (16, "uniform", 0),
                                               (100, "lowrank", 1), (7, "grid", 0), (48, "outliers", 0), (33, "offset", 0),
-                                              (768, "lowrank", 0), (5, "constant", 0), (124, "lowrank", 0)])
+                                              (768, "lowrank", 0), (5, "constant", 0), (124, "lowrank", 0), (40, "heavytail", 0)])
 def test_filter_changes_nothing_and_rejects(eng, oracle, monkeypatch, dim, kind_, metric):
     ida, kind = eng
     if kind == "emu" and dim == 768:
