@@ -251,7 +251,6 @@ struct Knobs {
     bool tie_spill_first = false; // IDIST_TIE_SPILL=1: strict ties go to the HBM bags at the first overflow instead of growing the LDS region first (test knob)
     bool events = true;           // IDIST_KERNEL_EVENTS=0: no HIP events around the search kernels (idist_search_ctx_kernel_times then has nothing)
     bool filter = true;           // IDIST_FILTER=0: wide on-chip walks without the reject filter (test / A-B knob)
-    uint32_t filter_waves = 0;    // IDIST_FILTER_WAVES=1|2: waves per SIMD of the filtered wide walk (0 = the policy's choice; A-B knob)
     bool tab_ids = false;         // IDIST_TAB_FORMAT=ids: the on-chip set always keeps full ids (4 per bucket, frozen at 7/8), never
                                   // 16-bit quotients (8 per bucket, single ids overflow) (test / A-B knob)
     bool tab_q16 = false;         // IDIST_TAB_FORMAT=q16: quotients wherever they apply, also where the policy would keep ids
@@ -270,7 +269,6 @@ struct Knobs {
         if (const char* e = test_env("IDIST_WALK")) k.classic = e[0] == 'c';      // (honoured by the test build only, see variants_check)
         if (const char* e = test_env("IDIST_BLOOM")) k.bloom = e[0] != '0';
         if (const char* e = test_env("IDIST_FILTER")) k.filter = e[0] != '0';
-        if (const char* e = test_env("IDIST_FILTER_WAVES")) k.filter_waves = (uint32_t)std::min(2, std::max(0, atoi(e)));
         if (const char* e = test_env("IDIST_VISITED")) { k.vis_bitmap = e[0] == 'b'; k.vis_onchip = e[0] == 'o'; }
         if (const char* e = test_env("IDIST_NO_ZERO_COPY")) k.no_zero_copy = e[0] != '0';
         if (const char* e = test_env("IDIST_TAB_FORMAT")) { k.tab_ids = e[0] == 'i'; k.tab_q16 = e[0] == 'q'; }
@@ -1224,8 +1222,10 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const bool use_filter = wide_on_chip && !quad && filter_ok;
     if (use_filter) CHK(filter_ensure(ix));
     const bool filtered = use_filter && ix->filt_state.load(std::memory_order_acquire) == 1;
+    // (every other wide walk — unfiltered indexes, IDIST_TAB_FORMAT=ids, the classic test walks, n beyond the quotient form's reach —
+    //  runs the round-5 kernels, compiled WITHOUT the filter: carrying its registers cost the 1024-d search 15 %)
     uint32_t fw = 1;
-    if (filtered && !ctx->knobs.classic && !ctx->knobs.tab_ids) fw = ctx->knobs.filter_waves ? ctx->knobs.filter_waves : kFilterWaves;
+    if (filtered && !ctx->knobs.classic && !ctx->knobs.tab_ids) fw = kFilterWaves;
     if (fw > 1) {
         uint32_t l = ctx->knobs.tab_log2 ? std::min(tab_fit, ctx->knobs.tab_log2) : tab_fit;
         while (l > 10u && smem_bytes(ix->L.stride, a.wcap, false, 1u << l, a.vis.dirty_words, false) * 4u * fw > (size_t)160 * 1024) l--;
@@ -1290,7 +1290,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const uint32_t grid = std::min(std::min(nq, ctx->slots), resident);
     [[maybe_unused]] const bool classic = ctx->knobs.classic;   // (test build: IDIST_VARIANT_SEARCH_*)
     IndexView view = ix->view();
-    if (!filtered) view.f = FilterView{};
+    if (!thin) view.f = FilterView{};
     a.queue_base = ctx->queue_base;
     a.status_host = status_host && grid <= idist_search_ctx::kIoStatusSlots ? status_host : nullptr;
     a.done_host = done_host;
@@ -1306,12 +1306,12 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
 #ifdef IDIST_VARIANTS
 #define IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_)                                                    \
     else if (on_chip && classic && q16) {                                                                   \
-        auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkClassic, 0, false, 1, true, false, true))>;  \
+        auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true, false, true)>;  \
         IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                                  \
     }
 #define IDIST_VARIANT_SEARCH_ONCHIP_IDS(NB_, RS_, TAIL_)                                                    \
     else if (on_chip && classic) {                                                                          \
-        auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkClassic, 0, false, 1, true))>;               \
+        auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkClassic, 0, false, 1, true)>;               \
         IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                                  \
     }
 #define IDIST_VARIANT_SEARCH_BITMAP(NB_, RS_, TAIL_)                                                        \
@@ -1336,13 +1336,13 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_thin_filter(2)>;                         \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_) else if (w2) {                          \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true))>; \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } else if (on_chip && q16) {                                                               \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true, false, true))>; \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } IDIST_VARIANT_SEARCH_ONCHIP_IDS(NB_, RS_, TAIL_) else if (on_chip) {                     \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true))>;  \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true)>;  \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } else if (lat) {                                                                          \
             auto kS = search_kernel<NB_, RS_, TAIL_, kWalkLatency>;                                \

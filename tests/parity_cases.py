@@ -15,15 +15,14 @@ INVALID = 0xFFFFFFFF
 # quotients, single ids overflow to the HBM bitmap — forced early with a tiny set; IDIST_TAB_FORMAT=ids: full ids,
 # frozen at 7/8); IDIST_VISITED=bitmap selects the bitmap + Bloom-filter walks (classic / latency / overlap by batch
 # width and IDIST_WALK).  All must give the reference's results.
-# Wide on-chip walks run with the reject filter in front of their distance passes (tests/test_filter.py; IDIST_FILTER=0: without):
-# as two thin waves per SIMD on the quotient set (default) or on the fat one-wave-per-SIMD layouts (IDIST_FILTER_WAVES=1).
+# Wide on-chip walks on the quotient set run with the reject filter in front of their distance passes, as two thin waves per SIMD
+# (tests/test_filter.py; IDIST_FILTER=0: the round-5 kernels without it).  The id-set, classic and long-walk variants are unfiltered.
 SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by index size and ef_search)", {}),
                    ("on-chip, quotient set (filtered: two thin waves per SIMD)", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "q16"}),
-                   ("on-chip, quotient set, one fat wave per SIMD, filtered", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "q16", "IDIST_FILTER_WAVES": "1"}),
                    ("on-chip, quotient set, no filter", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "q16", "IDIST_FILTER": "0"}),
                    ("four waves per query, quotient set", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_FORMAT": "q16"}),
                    ("long-walk form: two 256-register waves per SIMD on the quotient set (policy: ef_search >= 512 at 300-d, unfiltered indexes)",
-                    {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "q16", "IDIST_W2_EF": "0", "IDIST_FILTER_WAVES": "1"}),
+                    {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "q16", "IDIST_W2_EF": "0", "IDIST_FILTER": "0"}),
                    ("four waves per query, 512-B quotient set (256 ids) then bitmap", {"IDIST_QUAD_NQ": "4000000000", "IDIST_TAB_LOG2": "7"}),
                    ("on-chip classic", {"IDIST_WALK": "classic", "IDIST_VISITED": "onchip"}),
                    ("on-chip, full ids", {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip", "IDIST_TAB_FORMAT": "ids"}),
@@ -119,7 +118,7 @@ def search_variant(env):
             swapped = None
     keys = ("IDIST_LATENCY_NQ", "IDIST_WALK", "IDIST_VISITED", "IDIST_TAB_LOG2", "IDIST_QUAD_NQ", "IDIST_BUILD_A2",
             "IDIST_TAB_FORMAT", "IDIST_BUILD_NO_FAST", "IDIST_BUILD_QUAD", "IDIST_BUILD_A_REGS", "IDIST_W2_EF", "IDIST_FILTER",
-            "IDIST_FILTER_WAVES", "IDIST_BUILD_FILTER")
+            "IDIST_BUILD_FILTER")
     old = {k: os.environ.get(k) for k in keys}
     for k in keys:
         os.environ.pop(k, None)

@@ -10,12 +10,9 @@ import parity_cases as pc
 from engines import engine_params
 
 ON_CHIP = {"IDIST_QUAD_NQ": "0", "IDIST_VISITED": "onchip"}          # wide on-chip walk whatever the index size (test-build knobs)
-WALKS = (("two thin waves per SIMD (the default of a filtered wide walk)", dict(ON_CHIP)),
-         ("thin, tiny quotient set: ids overflow to the bitmap (second pass)", {**ON_CHIP, "IDIST_TAB_LOG2": "7"}),
-         ("fat wave, id set", {**ON_CHIP, "IDIST_TAB_FORMAT": "ids"}),
-         ("fat wave, quotient set", {**ON_CHIP, "IDIST_TAB_FORMAT": "q16", "IDIST_FILTER_WAVES": "1"}),
-         ("two 256-register waves per SIMD (long-walk form)", {**ON_CHIP, "IDIST_TAB_FORMAT": "q16", "IDIST_W2_EF": "0", "IDIST_FILTER_WAVES": "1"}),
-         ("classic", {"IDIST_WALK": "classic", "IDIST_VISITED": "onchip"}))
+WALKS = (("two thin waves per SIMD on the quotient set (the filtered wide walk)", dict(ON_CHIP)),
+         ("the same with a tiny quotient set: ids overflow to the bitmap (second pass)", {**ON_CHIP, "IDIST_TAB_LOG2": "7"}),
+         ("... and a mid-sized one", {**ON_CHIP, "IDIST_TAB_LOG2": "10"}))
 
 
 @pytest.fixture(params=engine_params())
