@@ -592,7 +592,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // Which register budget the descents take (same graphs either way; round 5):
     //   * the 128-d instantiation (4 blocks): one fat wave per SIMD at EVERY size — C2 100k x 128: 0.110 against 0.121 s (five to
     //     eight thin waves per CU: 0.117-0.122 s); 300k / 600k / 1M x 128: 0.245 / 0.449 / 0.713 s against 0.286 / 0.550 / 0.915 s
-    //     (profiles/probe_r05c_build_descent_waves_c2.jsonl, probe_r05p_build_regs_mid_size_short_rows.jsonl);
+    //     (profiles/r05/probe_r05c_build_descent_waves_c2.jsonl, probe_r05p_build_regs_mid_size_short_rows.jsonl);
     //   * 300-d and 768-d rows: two 256-register waves per SIMD, also where the index sits in the Infinity Cache (C3 1.26 against
     //     1.29-1.32 s, C4 2.78-2.83 against 3.00-3.06 s; 40k x 768: 0.139 against 0.153 s; 60k-200k x 300: within 2 %,
     //     probe_r05q_build_regs_cache_resident_long_rows.jsonl);
@@ -604,7 +604,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     if (const char* e = test_env("IDIST_BUILD_A_REGS")) a_regs256 = tab16 && atoi(e) == 256;
     // (Fat descent waves take a SIMD's whole register file: where four of them sit on a CU, nothing of the update stream runs until
     //  one retires — at 1024-d the selection's launches stretch to the descents' 13 ms and a step's period is 16.5 ms for 12.9 ms of
-    //  descents, profiles/trace_chain_r05i_build_500k_dim1024.json.  Measured and not kept: fewer descent waves per step, so that some
+    //  descents, profiles/r05/trace_chain_r05i_build_500k_dim1024.json.  Measured and not kept: fewer descent waves per step, so that some
     //  SIMDs stay free — 960 / 896 / 768 waves build 500k x 1024-d in 2.25 / 2.31 / 2.51 s against 2.20 s, probe_r05j; the update
     //  streams at the highest priority — no difference at 1024 / 512 / 768 / 300-d, probe_r05k.)
     // steps of at most two insertions per CU run four waves per insertion (IDIST_BUILD_QUAD=0: never)
@@ -797,7 +797,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             const bool alt = stream_mode == 2 || (stream_mode == 1 && B <= quad_B);   // this step on the extra streams
             // a sequential step (B = 1: the top layer, the first 63 points) depends on the whole previous step anyway: all of its
             // launches go to the update stream — same-stream boundaries (~2 us) instead of three cross-stream event hops (~27 us each
-            // in the trace of profiles/trace_chain_r05b_build_c2.json: 74 of the 179 us such a step took)
+            // in the trace of profiles/r05/trace_chain_r05b_build_c2.json: 74 of the 179 us such a step took)
             // Only where every descent stream has its own queue head, visited bitmaps and tie bags (two_a): with ONE set of them (a build
             // on the HBM tie bags, IDIST_BUILD_STREAMS=off) the last sequential step's descent on s2 and the next, concurrent step's
             // descent on s1 — which waits for the step BEFORE it only — would share them.
@@ -1071,7 +1071,7 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
 //     vs 0.628 / 0.620 / 0.611 of spec at 650 / 800 / 1000; beyond the merge's reach too: 0.628 vs 0.565 at ef 1000 in
 //     probe_r04k).  Rows of >= 256 floats: on chip as far as LDS allows; shorter rows: the line through the 128-d (~180) and
 //     300-d (~600) crossovers.
-//   * round 5 (profiles/probe_r05m_walk_policy_cache_resident.jsonl, probe_r05n_walk_policy_by_size_and_row.jsonl: on-chip walk vs
+//   * round 5 (profiles/r05/probe_r05m_walk_policy_cache_resident.jsonl, probe_r05n_walk_policy_by_size_and_row.jsonl: on-chip walk vs
 //     bitmap walk at 9 more shapes): which walk wins near the Infinity Cache depends on the ROW LENGTH, not on residency alone.
 //     Rows of >= 256 floats: the on-chip walk wins by 5-8 % also where the index sits in the cache (100k x 300: 7.97 vs 8.51 ms,
 //     40k x 768: 17.2 vs 18.1 ms per 10k queries at ef 100; the same at ef 150-800).  Shorter rows: the bitmap walk wins well BEYOND
@@ -1083,7 +1083,7 @@ idist_status ensure_slots(idist_search_ctx* ctx, uint32_t want, hipStream_t stre
 //     4 x 8 rows x 256 B = 8 KB on the wire per wave at 64-d, and the bitmap walk wins at EVERY size — 4M x 64 (1 GB): 5.93 / 10.7 /
 //     20.1 ms against 7.13 / 14.9 / 31.0 ms at ef 100 / 200 / 400; at 100-d (3 blocks) it wins from ef ~150 on (3M x 100: 14.9 / 27.3
 //     against 16.3 / 34.0 ms at ef 200 / 400, a tie at ef 100); 200-d rows behave like the 128-d instantiation (2M x 200: on chip 9.83 /
-//     19.3 against 11.5 / 21.1 ms) — profiles/probe_r05u_walk_policy_short_rt_rows_large.jsonl.
+//     19.3 against 11.5 / 21.1 ms) — profiles/r05/probe_r05u_walk_policy_short_rt_rows_large.jsonl.
 inline uint32_t on_chip_max_ef(uint32_t stride_floats, size_t index_bytes, bool runtime_geometry) {
     if (stride_floats >= 256u) return 1536u;       // (as far as W and the set fit a wave's LDS: tab_fit in launch_search)
     if (runtime_geometry && stride_floats <= 64u) return 0u;         // never: see above
@@ -1101,13 +1101,13 @@ constexpr uint32_t kLongWalkEf = 512u;   // ef_search from which wide on-chip ba
 // Long walks and where the visited bitmaps land (round 5, measured, nothing kept): ef_search 800 at 1M points test-and-sets the HBM
 // bitmaps ~36k times per query, and five fresh contexts on ONE index in one process answer the same 10k queries in 72.5 / 72.9 / 79.1 /
 // 82.3 / 82.4 ms while fresh replicas of the index behind fresh contexts change nothing — the spread between fresh processes is the
-// CONTEXT's allocation, not the index's (profiles/probe_r05b_placement_ef800_contexts_vs_replicas_c3.jsonl).  The pattern alone
+// CONTEXT's allocation, not the index's (profiles/r05/probe_r05b_placement_ef800_contexts_vs_replicas_c3.jsonl).  The pattern alone
 // (scripts/micro/bitmap_placement.hip) is placement-independent; beside random row gathers it shows the same discrete levels (3 %): the
 // 192 MB of hot bitmap lines and the row gathers compete for the 256-MiB Infinity Cache, and how well the bitmaps stay in it depends on
 // physical placement.  Choosing among four candidate allocations by timing the real kernel (round 1's cure for the byte array) found a
 // fast one on one box (four of five processes at 74-76 ms) and none on the next (five of five at 82.7 ms) for ~0.2 s per context: not
 // kept.  Gathering the rows with the non-temporal hint (leaving the cache to the bitmaps) costs 11-15 % at every ef_search and 30 % of
-// the build (`make nt`, profiles/probe_r05e_rows_nontemporal_ab_c3.jsonl): the row gathers live on Infinity-Cache hits too.
+// the build (`make nt`, profiles/r05/probe_r05e_rows_nontemporal_ab_c3.jsonl): the row gathers live on Infinity-Cache hits too.
 // The compact copy of the rows behind the walk's reject filter (FilterView): made once per index, here.  The lattice [lo, lo + 255
 // step] comes from a sample of the rows (mean +- 5 sigma of the coordinates, clipped to the sample's range): its choice decides how
 // many candidates the filter can reject, never a result — a coordinate outside it is clamped and its error is part of the row's
@@ -1247,7 +1247,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // Measured at 300-d (profiles/r04/probe_r04k_ef_paths_two_waves_per_simd_c3.jsonl: ef 650 / 800 / 1000 at 0.704 / 0.690 / 0.651 of
     // spec against 0.653 / 0.639 / 0.628 for the fat waves, 0.787 against 0.795 at ef 400): from ef_search 512 on, for that row
     // geometry; other geometries keep the fat waves until they are measured (IDIST_W2_EF forces either way).
-    // Round 5 (profiles/probe_r05r_long_walks_two_waves_other_geometries.jsonl): the same holds for runtime-geometry rows the
+    // Round 5 (profiles/r05/probe_r05r_long_walks_two_waves_other_geometries.jsonl): the same holds for runtime-geometry rows the
     // 256-register tile keeps whole in flight (1M x 384-d: ef 600 / 800 at 79.1 / 105.1 ms against 88.5 / 114.6 ms, ef 400 within
     // 2 %); not for 768-d (fat waves 1 % ahead at ef 400-800) and not for 128-d (thin waves 43 % slower at ef 400).
     const bool w2_geometry = (ix->L.nb == 9 && ix->L.rs == 1 && ix->L.tail == 1) || (rt_rows && ix->L.stride >= 256u && ix->L.nb <= 12u);

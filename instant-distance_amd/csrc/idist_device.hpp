@@ -579,7 +579,7 @@ constexpr int rounds_in_flight() {
 // registers: the build's descents) 2 x 3 x 4 = 96; the many-small-waves bitmap walks (16 per CU: 128 registers each) 2 x 1 x 4 = 32
 // (two waves per SIMD, 256 registers: <6 blocks, 3 rounds> = 2 x 3 x 6 float4 = 144 data registers, 36 KB on the wire per wave and a
 //  WHOLE row of up to 12 blocks (384-d) in flight; the <4, 3> tile of round 4 kept 8 of 12 blocks in flight and built 1M x 384-d in
-//  2.57-2.67 s where this one takes 1.75 s — profiles/probe_r05f_build_rt_tiles_dim384.jsonl.  Measurement builds override both.)
+//  2.57-2.67 s where this one takes 1.75 s — profiles/r05/probe_r05f_build_rt_tiles_dim384.jsonl.  Measurement builds override both.)
 #ifndef IDIST_RT2_ROUNDS
 #define IDIST_RT2_ROUNDS 3
 #endif
@@ -1804,7 +1804,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
     // four-wave walk with the visited set on chip: the helpers work one expansion ahead (QuadCtl)
     // the helpers work one expansion ahead — for the compile-time row geometries only: with the runtime-geometry tile the work-ahead
     // COSTS a scalar call 9-26 % (1M x 200 / 384-d, 500k x 1024-d: 0.526 / 0.656 / 2.40 ms without it against 0.576 / 0.780 / 3.23 ms
-    // with it; 300-d: 0.478 with, 0.479 without — profiles/probe_r05l_single_query_rt_rows_ab.jsonl; round 4 measured it at 300-d and
+    // with it; 300-d: 0.478 with, 0.479 without — profiles/r05/probe_r05l_single_query_rt_rows_ab.jsonl; round 4 measured it at 300-d and
     // 768-d only)
     constexpr bool kSpec = walk_quad(LAT) && walk_vis_lds(LAT) && PFA && NB >= 0;
     [[maybe_unused]] uint32_t sq_pid = kInvalid;          // the candidate whose row the helpers were given (wave-uniform)

@@ -1,5 +1,5 @@
 // build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 -o /tmp/bp scripts/micro/bitmap_placement.hip && /tmp/bp
-// Why does a long walk's time depend on which allocation its visited bitmaps got (profiles/probe_r05b_placement_*)?
+// Why does a long walk's time depend on which allocation its visited bitmaps got (profiles/r05/probe_r05b_placement_*)?
 // K allocations of 2048 slots x 125,056 B (the C3 geometry), each driven by 1536 waves doing DEPENDENT random test-and-set atomics on
 // their own slot (the long walk's pattern: ~36 touches per 128-B line and query), (a) alone, (b) beside waves that stream random
 // 1216-B rows out of a 1.2-GB array (the walk's row gathers, which compete for the Infinity Cache).  One JSON line per allocation.
