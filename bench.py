@@ -15,11 +15,12 @@ tests/test_distributed_gloo.py makes gloo / cpu Jobs around the emulator build o
 functions at world sizes 2 and 3, so the N > 1 control flow has executed before an 8-GPU lease runs it.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     HBM bound: algorithmic bytes per launch (B_q = n_dist*4*D + n_exp0*256 +
-               n_expU*128 + 8*ef summed over the launch's queries, counted by the kernel itself
-               and equal to the oracle's counters by bit-exactness) / average kernel duration
-               measured with HIP events on the launch stream; `traffic` = fabric bytes per launch from two child passes
-               of this command under rocprofv3 --pmc, calibrated in the same pass (N = 1).
+  roofline     HBM bound: the bytes one launch requests by the kernel's own counters — f32 rows of the pushed candidates the
+               reject filter did not turn down + compact rows of the candidates it examined + adjacency rows +
+               results; = SURVEY 8(d)'s B_q = n_dist*4*D + n_exp0*256 + n_expU*128 + 8*ef when nothing is filtered, and that
+               figure is kept beside it as `survey_8d` — / average kernel duration measured with HIP events on the launch
+               stream; `traffic` = fabric bytes per launch from two child passes of this command under rocprofv3 --pmc,
+               calibrated in the same pass on both request patterns (N = 1).
   cpu_baseline the CPU oracle (restated reference, NOT the Rust crate) searching the SAME graph
                on the host cores for a bounded query sample (rank 0 at N = 1 only).
   parity       (N = 1) the oracle's answers for a query sample at ef_search 100 / 200 / the timed one compared with

@@ -635,10 +635,23 @@ constexpr int filt_chunks() {
     const uint32_t stride = used < 16u ? 16u : ((used + 15u) & ~15u);
     return (int)((filt_stride(stride) + 127u) / 128u);
 }
-// rows of one filter pass in flight: 8 * FR, bounded by the registers a row's bytes take (4 * NCH per lane)
-template <int NCH, int WALK> constexpr int filt_rounds() {
-    const int budget = walk_waves(WALK) == 1 ? 256 : 56;
-    const int r = budget / (4 * NCH);
+// The compile-time geometries' compact rows all end in HALF a chunk (320 = 2 x 128 + 64, 192, 832): that half is read as 8 bytes
+// per lane by all 8 lanes of a group (T8) instead of 16 bytes by four of them — two registers of row data per lane and round less,
+// which is what lets a thin wave keep all 64 rows of an expansion in flight at 300-d (8 x 10 registers).
+template <int NB, int RS, int TAIL>
+constexpr bool filt_tail8() {
+    if (NB < 0) return false;
+    const uint32_t used = 32u * (uint32_t)NB + 8u * (uint32_t)RS + 4u * (uint32_t)TAIL;
+    const uint32_t stride = used < 16u ? 16u : ((used + 15u) & ~15u);
+    return (filt_stride(stride) & 127u) == 64u;
+}
+// rows of one filter pass in flight: 8 * FR, bounded by the registers a row's bytes take per lane
+template <int NCH, bool T8, int WALK> constexpr int filt_rounds() {
+    const int per_round = 4 * (T8 ? NCH - 1 : NCH) + (T8 ? 2 : 0);
+    // thin waves (256 registers): all 64 rows of an expansion at 300-d / 128-d (8 x 10 / 8 x 6 registers); long rows and the
+    // runtime-geometry tile keep what leaves the kernel without scratch (768-d: 2 x 26, the query's byte planes take 52 more)
+    const int budget = walk_waves(WALK) == 1 ? 256 : (NCH >= 5 ? 56 : (T8 ? 80 : 64));
+    const int r = budget / per_round;
     return r > 8 ? 8 : (r < 2 ? 2 : r);
 }
 
@@ -653,27 +666,34 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
 // A query on the filter's lattice, held in registers for the whole walk: lane j of every 8-lane group keeps the bytes of the
 // positions its loads of a compact row cover (chunk c: positions 128 c + 16 j ... + 15) — the 16-bit coordinate Q split into a
 // high and a low byte plane, so that sum Q u = 256 (h . u) + (l . u) is two v_dot4_u32_u8 per dword of row.
-template <int NCH>
+template <int NCH, bool T8 = false>
 struct FilterQ {
-    uint4 h[NCH], l[NCH];
+    static constexpr int NCF = T8 ? NCH - 1 : NCH;      // full 128-B chunks (16 bytes per lane); T8: + one half chunk (8 bytes per lane)
+    uint4 h[NCF > 0 ? NCF : 1], l[NCF > 0 ? NCF : 1];
+    uint2 ht, lt;
     float eq = 0.0f;        // |q - q^|_2, rounded up (NaN for a query with a NaN coordinate: nothing is ever rejected)
     uint64_t sq = 0;        // sum Q^2
     mutable bool on = false; // (a walk switches its own filter off when it is not paying, dist_pass_filtered)
     mutable uint32_t seen = 0, rejected = 0;   // per walk; search_kernel adds them to the context's counters when the query ends
 };
-template <int NCH>
-__device__ __forceinline__ void filter_stage_query(const IndexView& ix, const float* q, FilterQ<NCH>& fq) {
-    fq.on = ix.f.rows != nullptr && ix.f.fstride <= 128u * (uint32_t)NCH;
+template <int NCH, bool T8>
+__device__ __forceinline__ void filter_stage_query(const IndexView& ix, const float* q, FilterQ<NCH, T8>& fq) {
+    constexpr int NCF = FilterQ<NCH, T8>::NCF;
+    fq.on = ix.f.rows != nullptr && ix.f.fstride <= 128u * (uint32_t)NCH && (!T8 || ix.f.fstride == 128u * (uint32_t)NCF + 64u);
+    fq.ht = make_uint2(0u, 0u);
+    fq.lt = make_uint2(0u, 0u);
     if (!fq.on) return;
     const int j = lane_id() & 7;
     float e2 = 0.0f, mx = 0.0f;
     uint32_t sq_lo = 0, sq_hi = 0;
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
+    for (int c = 0; c < NCF + (T8 ? 1 : 0); c++) {
         uint32_t hw[4] = {0u, 0u, 0u, 0u}, lw[4] = {0u, 0u, 0u, 0u};
+        const bool tail = T8 && c == NCF;               // the half chunk: 8 bytes per lane
 #pragma unroll
         for (int b = 0; b < 16; b++) {
-            const uint32_t pos = 128u * (uint32_t)c + 16u * (uint32_t)j + (uint32_t)b;
+            if (tail && b >= 8) break;
+            const uint32_t pos = 128u * (uint32_t)c + (tail ? 8u : 16u) * (uint32_t)j + (uint32_t)b;
             if (pos < ix.stride && natural_pos(pos, ix.nb) < ix.dim) {       // (padding: Q = u = 0 by construction, no error either side)
                 const float v = q[pos];
                 const float t = (v - ix.f.lo) * ix.f.qscale;
@@ -689,8 +709,13 @@ __device__ __forceinline__ void filter_stage_query(const IndexView& ix, const fl
                 lw[b >> 2] |= (Q & 255u) << (8 * (b & 3));
             }
         }
-        fq.h[c] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-        fq.l[c] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        if (tail) {
+            fq.ht = make_uint2(hw[0], hw[1]);
+            fq.lt = make_uint2(lw[0], lw[1]);
+        } else {
+            fq.h[c] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            fq.l[c] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        }
     }
     // the 8 lanes of a group cover the row once: totals over the group (every group computes the same)
     uint64_t sq = ((uint64_t)sq_hi << 32) | sq_lo;
@@ -721,24 +746,30 @@ __device__ __forceinline__ uint32_t group_total_u32(uint32_t v) {           // s
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad's sum
     return v;
 }
-template <int NCH, int FR, class Mid = NoMid, bool BOUND = false>
-__device__ __forceinline__ void filter_rounds(const IndexView& ix, const FilterQ<NCH>& fq, const uint32_t* act_pid, uint32_t* act_dist,
+template <int NCH, bool T8, int FR, class Mid = NoMid, bool BOUND = false>
+__device__ __forceinline__ void filter_rounds(const IndexView& ix, const FilterQ<NCH, T8>& fq, const uint32_t* act_pid, uint32_t* act_dist,
                                               int na, float st, Mid mid = Mid()) {
     static_assert(FR >= 1 && FR <= 8, "lane j of a group finishes round j");
+    constexpr int NCF = FilterQ<NCH, T8>::NCF;
+    constexpr int NCA = NCF > 0 ? NCF : 1;
     const int lane = lane_id();
     const int g = lane >> 3, j = lane & 7;
     const uint32_t fs = ix.f.fstride;
     for (int base = 0; base < na; base += 8 * FR) {
-        uint4 p[FR][NCH];
+        uint4 p[FR][NCA];
+        uint2 pt[FR];
 #pragma unroll
         for (int r = 0; r < FR; r++) {
             const int k = base + 8 * r + g;
-            const uint8_t* row = ix.f.rows + (size_t)act_pid[k < na ? k : 0] * fs + 16u * (uint32_t)j;
+            const uint8_t* rowb = ix.f.rows + (size_t)act_pid[k < na ? k : 0] * fs;
+            const uint8_t* row = rowb + 16u * (uint32_t)j;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
+            for (int c = 0; c < NCF; c++) {
                 p[r][c] = make_uint4(0u, 0u, 0u, 0u);
-                if (k < na && 128u * (uint32_t)c + 16u * (uint32_t)j < fs) p[r][c] = *reinterpret_cast<const uint4*>(row + 128u * (uint32_t)c);
+                if (k < na && (T8 || 128u * (uint32_t)c + 16u * (uint32_t)j < fs)) p[r][c] = *reinterpret_cast<const uint4*>(row + 128u * (uint32_t)c);
             }
+            pt[r] = make_uint2(0u, 0u);
+            if constexpr (T8) { if (k < na) pt[r] = *reinterpret_cast<const uint2*>(rowb + 128u * (uint32_t)NCF + 8u * (uint32_t)j); }
         }
         // the row this lane finishes: round j of the batch, its metadata {|p - p^| (f32 bits), sum u^2} sits in the row's last 8 bytes
         const int kf = base + 8 * j + g;
@@ -755,11 +786,15 @@ __device__ __forceinline__ void filter_rounds(const IndexView& ix, const FilterQ
         for (int r = 0; r < FR; r++) {
             uint32_t ah = 0u, al = 0u;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {                               // (the query's bytes are zero over the padding and the metadata)
+            for (int c = 0; c < NCF; c++) {                               // (the query's bytes are zero over the padding and the metadata)
                 ah = udot4(fq.h[c].x, p[r][c].x, ah); al = udot4(fq.l[c].x, p[r][c].x, al);
                 ah = udot4(fq.h[c].y, p[r][c].y, ah); al = udot4(fq.l[c].y, p[r][c].y, al);
                 ah = udot4(fq.h[c].z, p[r][c].z, ah); al = udot4(fq.l[c].z, p[r][c].z, al);
                 ah = udot4(fq.h[c].w, p[r][c].w, ah); al = udot4(fq.l[c].w, p[r][c].w, al);
+            }
+            if constexpr (T8) {
+                ah = udot4(fq.ht.x, pt[r].x, ah); al = udot4(fq.lt.x, pt[r].x, al);
+                ah = udot4(fq.ht.y, pt[r].y, ah); al = udot4(fq.lt.y, pt[r].y, al);
             }
             ah = group_total_u32(ah);
             al = group_total_u32(al);
@@ -789,16 +824,18 @@ __device__ __forceinline__ void filter_rounds(const IndexView& ix, const FilterQ
 // walk's ordinary pass.  act_dist[k] ends up as the canonical distance bits of id k, or kAbandoned — above every key of a full
 // `nearest`, so `push` turns it down exactly as it would have turned down the distance itself (core/lib.rs:712-714).
 // thr_bits = 0xFFFFFFFF (nearest not full yet, or a build descent: its distance log needs every distance): no filter.
+template <int NB, int RS, int TAIL> using FilterQFor = FilterQ<filt_chunks<NB, RS, TAIL>(), filt_tail8<NB, RS, TAIL>()>;
 template <int NB, int RS, int TAIL, int WALK, class Mid = NoMid>
-__device__ __forceinline__ void dist_pass_filtered(const IndexView& ix, const float* q, const FilterQ<filt_chunks<NB, RS, TAIL>()>& fq,
+__device__ __forceinline__ void dist_pass_filtered(const IndexView& ix, const float* q, const FilterQFor<NB, RS, TAIL>& fq,
                                                    uint32_t* act_pid, uint32_t* act_dist, int na, Mid mid, uint32_t thr_bits) {
     if constexpr (walk_filter(WALK)) {
         if (fq.on && thr_bits != 0xFFFFFFFFu && na > 0) {
             constexpr int NCH = filt_chunks<NB, RS, TAIL>();
+            constexpr bool T8 = filt_tail8<NB, RS, TAIL>();
             const int lane = lane_id();
             const float thr = __uint_as_float(thr_bits);
             const float st = ix.metric ? thr : __builtin_sqrtf(thr);
-            filter_rounds<NCH, filt_rounds<NCH, WALK>()>(ix, fq, act_pid, act_dist, na, st, mid);
+            filter_rounds<NCH, T8, filt_rounds<NCH, T8, WALK>()>(ix, fq, act_pid, act_dist, na, st, mid);
             wave_sync();
             const bool in = lane < na;
             const uint32_t pid = in ? act_pid[lane] : 0u;
@@ -1793,7 +1830,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                                              const float* q, WState& st, Visited& vis, uint32_t* act_pid,
                                              uint32_t* act_dist, Counters& ctr, bool is_zero, DistLog& dlog,
                                              QuadLead* quad = nullptr,
-                                             const FilterQ<filt_chunks<NB, RS, TAIL>()>& fq = FilterQ<filt_chunks<NB, RS, TAIL>()>()) {
+                                             const FilterQFor<NB, RS, TAIL>& fq = FilterQFor<NB, RS, TAIL>()) {
     const int lane = lane_id();
     uint32_t guard = 0;
     const bool row_lane = lane < row_stride && lane < links;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         wave_sync();
 
         // the query on the reject filter's lattice (walks compiled with it): registers, for the whole walk
-        FilterQ<filt_chunks<NB, RS, TAIL>()> fq;
+        FilterQFor<NB, RS, TAIL> fq;
         if constexpr (walk_filter(LAT)) filter_stage_query(ix, sm.q, fq);
 
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
@@ -387,6 +387,7 @@ __global__ __launch_bounds__(64) void filter_bound_kernel(IndexView ix, const fl
     const uint32_t chunks = (n_ids + 63u) / 64u;
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
     constexpr int NCH = filt_chunks<NB, RS, TAIL>();
+    constexpr bool T8 = filt_tail8<NB, RS, TAIL>();
     for (uint32_t w = blockIdx.x; w < nq * chunks; w += gridDim.x) {
         const uint32_t qi = w / chunks, c0 = (w % chunks) * 64u;
         wave_sync();
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(64) void filter_bound_kernel(IndexView ix, const fl
         wave_sync();
         for (uint32_t e = lane; e < ix.dim; e += 64) sm.q[blocked_pos(e, nb)] = queries[(size_t)qi * ix.dim + e];
         wave_sync();
-        FilterQ<NCH> fq;
+        FilterQ<NCH, T8> fq;
         filter_stage_query(ix, sm.q, fq);
         const uint32_t i = c0 + lane;
         uint32_t id = kInvalid;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(64) void filter_bound_kernel(IndexView ix, const fl
         const int my = __popcll(m & ((1ull << lane) - 1ull));
         if (ok) sm.act_pid[my] = id;
         wave_sync();
-        if (m) filter_rounds<NCH, 2, NoMid, true>(ix, fq, sm.act_pid, sm.act_dist, __popcll(m), 0.0f);
+        if (m) filter_rounds<NCH, T8, 2, NoMid, true>(ix, fq, sm.act_pid, sm.act_dist, __popcll(m), 0.0f);
         wave_sync();
         if (i < n_ids) out[(size_t)qi * n_ids + i] = ok ? __uint_as_float(sm.act_dist[my]) : 0.0f;
     }
@@ -559,7 +560,7 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
         *reinterpret_cast<float4*>(sm.q + o) = *reinterpret_cast<const float4*>(prow + o);
     wave_sync();
     // the new point on the reject filter's lattice (descents compiled with it, §4.5)
-    FilterQ<filt_chunks<NB, RS, TAIL>()> fq;
+    FilterQFor<NB, RS, TAIL> fq;
     if constexpr (walk_filter(LAT)) filter_stage_query(ix, sm.q, fq);
     // search.reset(), :443: the visited set was emptied when the slot's previous descent ended
     push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, dl);  // :444

@@ -32,6 +32,8 @@
 struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
 struct uint4 { uint32_t x, y, z, w; } __attribute__((aligned(16)));
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct uint2 { uint32_t x, y; } __attribute__((aligned(8)));
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 
 namespace emu {
 
