@@ -1207,12 +1207,16 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const bool cache_resident = long_rows ? row_bytes < kLongRowOnChipBytes : row_bytes <= kShortRowBitmapBytes;   // "served best by many small waves"
     // With the reject filter in front (round 6) the on-chip walk stays ahead at every ef_search the set fits — 1M x 128 at ef 200 / 400:
     // 8.5 / 15.4 ms against 10.6 / 20.8 ms on the bitmap walk, 4M x 64-d at ef 100 / 200: 5.1 / 10.3 against 5.9 / 11.8 — and the ef
-    // caps of on_chip_max_ef only bind for unfiltered indexes (compact rows beyond the filter's tiles, IDIST_FILTER=0).  Cache-resident
-    // short rows are a tie (C2: 3.62 against 3.85 ms at ef 100, 6.86 against 6.63 at ef 200) and keep the bitmap walk
-    // (profiles/probe_r06f_filter_policy.jsonl).
+    // caps of on_chip_max_ef only bind for unfiltered indexes (compact rows beyond the filter's tiles, IDIST_FILTER=0).  The
+    // cache-residency rule shrinks too: filtered long rows take it at every size (20k x 300: 3.46 against 5.87 ms; 40k x 768 did before),
+    // filtered short rows from the L2's reach on (8 x 4 MB: 100k x 128 = C2 3.44 against 3.80 ms at ef 100, 6.56 against 6.64 at ef 200,
+    // a tie at 400; 300k x 128 3.65 against 4.45; 400k x 200-d 4.71 against 7.48) — below it the bitmap walk's sixteen small waves per
+    // CU win (10k x 128: 1.98 against 2.83 ms, 50k x 64-d: 2.85 against 3.75) — profiles/probe_r06f_filter_policy.jsonl,
+    // probe_r06l_c2_policy.jsonl.
     const bool filter_ok = ctx->knobs.filter && filter_applies(ix);
+    const bool small_for_filter = !long_rows && row_bytes < ((size_t)32 << 20);
     const bool wide_on_chip = tab_fit && (ctx->knobs.vis_onchip || ctx->knobs.tab_log2 ||
-                                          ((filter_ok || ef <= on_chip_max_ef(ix->L.stride, row_bytes, rt_rows)) && !cache_resident));
+                                          (filter_ok ? !small_for_filter : (ef <= on_chip_max_ef(ix->L.stride, row_bytes, rt_rows) && !cache_resident)));
     const bool on_chip = quad || wide_on_chip;
     uint32_t tab_log2 = on_chip ? tab_fit : 0u;
     // The reject filter in front of the wide on-chip walks' distance passes (its compact rows are made on first use).  A filtered
