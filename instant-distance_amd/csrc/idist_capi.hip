@@ -1232,7 +1232,11 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     if (filtered && !ctx->knobs.classic && !ctx->knobs.tab_ids) fw = kFilterWaves;
     if (fw > 1) {
         uint32_t l = ctx->knobs.tab_log2 ? std::min(tab_fit, ctx->knobs.tab_log2) : tab_fit;
-        while (l > 10u && smem_bytes(ix->L.stride, a.wcap, false, 1u << l, a.vis.dirty_words, false) * 4u * fw > (size_t)160 * 1024) l--;
+        // (a smaller set addresses fewer ids in its 16-bit quotients: 10M points need the 16-KB set — C5 runs six or seven thin
+        //  waves per CU on it rather than eight on a set it cannot use)
+        while (l > 10u && smem_bytes(ix->L.stride, a.wcap, false, 1u << l, a.vis.dirty_words, false) * 4u * fw > (size_t)160 * 1024 &&
+               q16_applies(l - 1u, q16_universe_bits(ix->n, l - 1u)))
+            l--;
         if (q16_applies(l, q16_universe_bits(ix->n, l))) tab_log2 = l;
         else fw = 1;
     }

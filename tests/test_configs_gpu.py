@@ -50,6 +50,9 @@ def assert_config(out, n, dim, nq):
     assert set(cfg["ef_sweep_recall"]) >= {"100", "200"}
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and 0.0 < rf["frac"] < 1.0 and rf["kernel_ms_avg"] > 0
+    # the reject filter is at work at these shapes — a silent fall-back to the unfiltered walk would halve the rate
+    assert (rf["reject_filter"]["rejected_share"] or 0) > 0.8, rf["reject_filter"]
+    assert (out["build"]["reject_filter"]["rejected_share"] or 0) > 0.8, out["build"]["reject_filter"]
     assert out["build"]["n_updates_memoised"] + out["build"]["n_updates_full"] == out["build"]["n_updates"]
 
 
