@@ -1228,8 +1228,12 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const bool filtered = use_filter && ix->filt_state.load(std::memory_order_acquire) == 1;
     // (every other wide walk — unfiltered indexes, IDIST_TAB_FORMAT=ids, the classic test walks, n beyond the quotient form's reach —
     //  runs the round-5 kernels, compiled WITHOUT the filter: carrying its registers cost the 1024-d search 15 %)
+    // Long rows (compact rows beyond four chunks: 768-d) keep ONE fat wave per SIMD with the filter: a thin wave's registers hold 16
+    // of their compact rows and a quarter of an f32 row at a time — six or seven dependent round trips per expansion where the fat
+    // wave makes two (C5, ef 200: 162 ms fat against 213 ms thin per 65,536 queries; C4 a tie at 78-83 ms).
+    const bool fat_filtered = filtered && !ctx->knobs.classic && filt_stride(ix->L.stride) > 128u * (uint32_t)kFiltRtChunks;
     uint32_t fw = 1;
-    if (filtered && !ctx->knobs.classic && !ctx->knobs.tab_ids) fw = kFilterWaves;
+    if (filtered && !fat_filtered && !ctx->knobs.classic && !ctx->knobs.tab_ids) fw = kFilterWaves;
     if (fw > 1) {
         uint32_t l = ctx->knobs.tab_log2 ? std::min(tab_fit, ctx->knobs.tab_log2) : tab_fit;
         // (a smaller set addresses fewer ids in its 16-bit quotients: 10M points need the 16-KB set — C5 runs six or seven thin
@@ -1298,7 +1302,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     const uint32_t grid = std::min(std::min(nq, ctx->slots), resident);
     [[maybe_unused]] const bool classic = ctx->knobs.classic;   // (test build: IDIST_VARIANT_SEARCH_*)
     IndexView view = ix->view();
-    if (!thin) view.f = FilterView{};
+    if (!thin && !fat_filtered) view.f = FilterView{};
     a.queue_base = ctx->queue_base;
     a.status_host = status_host && grid <= idist_search_ctx::kIoStatusSlots ? status_host : nullptr;
     a.done_host = done_host;
@@ -1345,6 +1349,12 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_) else if (w2) {                          \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+        } else if (on_chip && q16 && fat_filtered) {                                               \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true, false, true))>; \
+            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+        } else if (on_chip && fat_filtered) {                                                      \
+            auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true))>; \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } else if (on_chip && q16) {                                                               \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
