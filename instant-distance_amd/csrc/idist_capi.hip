@@ -714,6 +714,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // IDIST_BUILD_FILTER=1 (test knob) forces it for every geometry the filter applies to.
     const char* bf_env = test_env("IDIST_BUILD_FILTER");
     bool build_filter = cfg.has_heuristic && !ext && tab16 && knobs.filter && filter_applies(ix) &&
+                        (has_template_geometry(ix->L) || filt_stride(ix->L.stride) <= 128u * (uint32_t)kFiltRtChunks) &&   // (the thin tile)
                         (bf_env ? bf_env[0] != '0' : ix->L.stride >= 256u);
     if (build_filter) {
         CHK(filter_ensure(ix));
@@ -1117,7 +1118,7 @@ constexpr uint32_t kLongWalkEf = 512u;   // ef_search from which wide on-chip ba
 // Geometries the search kernels have no filter tile for (compact rows beyond four 128-B chunks without a compile-time instantiation)
 // and indexes the copy finds no memory for simply run without it.
 bool filter_applies(const idist_index* ix) {
-    return ix->n > 0 && (has_template_geometry(ix->L) || filt_stride(ix->L.stride) <= 128u * (uint32_t)kFiltRtChunks);
+    return ix->n > 0 && (has_template_geometry(ix->L) || filt_stride(ix->L.stride) <= 128u * (uint32_t)kFiltRtChunksFat);
 }
 idist_status filter_ensure(const idist_index* ix) {
     if (ix->filt_state.load(std::memory_order_acquire) != 0) return IDIST_OK;

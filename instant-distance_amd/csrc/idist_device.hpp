@@ -66,7 +66,8 @@ struct FilterView {
     float slack = 0.0f;              // absolute slack of a query's own lattice error (f32 evaluation), per sqrt(dim) * magnitude
 };
 constexpr uint32_t filt_stride(uint32_t stride_floats) { return (stride_floats + 8u + 63u) & ~63u; }
-constexpr int kFiltRtChunks = 4;     // runtime-geometry rows: filtered while a compact row fits four 128-B chunks (dim <= 496)
+constexpr int kFiltRtChunks = 4;     // runtime-geometry rows on THIN filtered waves: a compact row of at most four 128-B chunks (dim <= 496)
+constexpr int kFiltRtChunksFat = 13; // ... on one fat filtered wave per SIMD (longer rows, like 768-d): thirteen chunks (dim <= 1656: 512-d, 1024-d, 1536-d)
 
 // Device view of an index (plain pointers; lives in kernel arguments).
 struct IndexView {
@@ -628,9 +629,10 @@ constexpr int walk_thin_filter(int waves = 2) {  // the walk code of a thin filt
     return walk_code(kWalkOverlap, 1, true, waves, true, false, true) | kWalkFilterBit | kWalkThinBit;
 }
 // 128-B chunks of a compact row (8 lanes x 16 B each; the last one may be half a chunk)
-template <int NB, int RS, int TAIL>
+// WALK: the walk code of the kernel (runtime geometries only: the fat filtered walk's tile is larger than the thin one's)
+template <int NB, int RS, int TAIL, int WALK = 0>
 constexpr int filt_chunks() {
-    if (NB < 0) return kFiltRtChunks;
+    if (NB < 0) return walk_is_thin(WALK) || ((WALK >> 19) & 1) == 0 ? kFiltRtChunks : kFiltRtChunksFat;
     const uint32_t used = 32u * (uint32_t)NB + 8u * (uint32_t)RS + 4u * (uint32_t)TAIL;
     const uint32_t stride = used < 16u ? 16u : ((used + 15u) & ~15u);
     return (int)((filt_stride(stride) + 127u) / 128u);
@@ -682,6 +684,8 @@ __device__ __forceinline__ void filter_stage_query(const IndexView& ix, const fl
     fq.on = ix.f.rows != nullptr && ix.f.fstride <= 128u * (uint32_t)NCH && (!T8 || ix.f.fstride == 128u * (uint32_t)NCF + 64u);
     fq.ht = make_uint2(0u, 0u);
     fq.lt = make_uint2(0u, 0u);
+#pragma unroll
+    for (int c = 0; c < (NCF > 0 ? NCF : 1); c++) fq.h[c] = fq.l[c] = make_uint4(0u, 0u, 0u, 0u);
     if (!fq.on) return;
     const int j = lane_id() & 7;
     float e2 = 0.0f, mx = 0.0f;
@@ -824,13 +828,13 @@ __device__ __forceinline__ void filter_rounds(const IndexView& ix, const FilterQ
 // walk's ordinary pass.  act_dist[k] ends up as the canonical distance bits of id k, or kAbandoned — above every key of a full
 // `nearest`, so `push` turns it down exactly as it would have turned down the distance itself (core/lib.rs:712-714).
 // thr_bits = 0xFFFFFFFF (nearest not full yet, or a build descent: its distance log needs every distance): no filter.
-template <int NB, int RS, int TAIL> using FilterQFor = FilterQ<filt_chunks<NB, RS, TAIL>(), filt_tail8<NB, RS, TAIL>()>;
+template <int NB, int RS, int TAIL, int WALK> using FilterQFor = FilterQ<filt_chunks<NB, RS, TAIL, WALK>(), filt_tail8<NB, RS, TAIL>()>;
 template <int NB, int RS, int TAIL, int WALK, class Mid = NoMid>
-__device__ __forceinline__ void dist_pass_filtered(const IndexView& ix, const float* q, const FilterQFor<NB, RS, TAIL>& fq,
+__device__ __forceinline__ void dist_pass_filtered(const IndexView& ix, const float* q, const FilterQFor<NB, RS, TAIL, WALK>& fq,
                                                    uint32_t* act_pid, uint32_t* act_dist, int na, Mid mid, uint32_t thr_bits) {
     if constexpr (walk_filter(WALK)) {
         if (fq.on && thr_bits != 0xFFFFFFFFu && na > 0) {
-            constexpr int NCH = filt_chunks<NB, RS, TAIL>();
+            constexpr int NCH = filt_chunks<NB, RS, TAIL, WALK>();
             constexpr bool T8 = filt_tail8<NB, RS, TAIL>();
             const int lane = lane_id();
             const float thr = __uint_as_float(thr_bits);
@@ -1830,7 +1834,7 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                                              const float* q, WState& st, Visited& vis, uint32_t* act_pid,
                                              uint32_t* act_dist, Counters& ctr, bool is_zero, DistLog& dlog,
                                              QuadLead* quad = nullptr,
-                                             const FilterQFor<NB, RS, TAIL>& fq = FilterQFor<NB, RS, TAIL>()) {
+                                             const FilterQFor<NB, RS, TAIL, LAT>& fq = FilterQFor<NB, RS, TAIL, LAT>()) {
     const int lane = lane_id();
     uint32_t guard = 0;
     const bool row_lane = lane < row_stride && lane < links;

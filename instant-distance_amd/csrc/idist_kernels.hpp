@@ -274,7 +274,7 @@ __global__ __launch_bounds__(walk_quad(LAT) ? 256 : 64) IDIST_WAVES_ATTR(LAT) vo
         wave_sync();
 
         // the query on the reject filter's lattice (walks compiled with it): registers, for the whole walk
-        FilterQFor<NB, RS, TAIL> fq;
+        FilterQFor<NB, RS, TAIL, LAT> fq;
         if constexpr (walk_filter(LAT)) filter_stage_query(ix, sm.q, fq);
 
         WState st{sm.W, 0, 1, 0, 0u, (int)a.tie_cap};
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64) void filter_bound_kernel(IndexView ix, const fl
     const int lane = lane_id();
     const uint32_t chunks = (n_ids + 63u) / 64u;
     const uint32_t nb = NB >= 0 ? (uint32_t)NB : ix.nb;
-    constexpr int NCH = filt_chunks<NB, RS, TAIL>();
+    constexpr int NCH = filt_chunks<NB, RS, TAIL, kWalkFilterBit>();       // (runtime geometries: the larger tile)
     constexpr bool T8 = filt_tail8<NB, RS, TAIL>();
     for (uint32_t w = blockIdx.x; w < nq * chunks; w += gridDim.x) {
         const uint32_t qi = w / chunks, c0 = (w % chunks) * 64u;
@@ -560,7 +560,7 @@ __device__ __forceinline__ void insert_descent(const IndexView& ix, const BuildA
         *reinterpret_cast<float4*>(sm.q + o) = *reinterpret_cast<const float4*>(prow + o);
     wave_sync();
     // the new point on the reject filter's lattice (descents compiled with it, §4.5)
-    FilterQFor<NB, RS, TAIL> fq;
+    FilterQFor<NB, RS, TAIL, LAT> fq;
     if constexpr (walk_filter(LAT)) filter_stage_query(ix, sm.q, fq);
     // search.reset(), :443: the visited set was emptied when the slot's previous descent ended
     push_entry<NB, RS, TAIL>(ix, sm.q, st, vis, sm.act_pid, sm.act_dist, tot, dl);  // :444

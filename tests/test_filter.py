@@ -41,11 +41,12 @@ def _data(rng, kind_, n, dim):
 
 @pytest.mark.parametrize("dim,kind_,metric", [(128, "lowrank", 0), (300, "lowrank", 0), (300, "uniform", 1), (16, "uniform", 0),
                                               (100, "lowrank", 1), (7, "grid", 0), (48, "outliers", 0), (33, "offset", 0),
-                                              (768, "lowrank", 0), (5, "constant", 0), (124, "lowrank", 0), (40, "heavytail", 0)])
+                                              (768, "lowrank", 0), (5, "constant", 0), (124, "lowrank", 0), (40, "heavytail", 0),
+                                              (512, "lowrank", 0), (1024, "lowrank", 1)])
 def test_filter_changes_nothing_and_rejects(eng, oracle, monkeypatch, dim, kind_, metric):
     ida, kind = eng
-    if kind == "emu" and dim == 768:
-        pytest.skip("768-d under the emulator: covered on the GPU")
+    if kind == "emu" and dim in (768, 1024):
+        pytest.skip("768-d / 1024-d under the emulator: covered on the GPU (512-d runs the same fat filtered walk here)")
     pc.use_test_build(monkeypatch)                     # (the walk knobs and the counters exist in the test build only)
     rng = np.random.default_rng(1000 + dim)
     n, ef = S(kind, 260, 20000), S(kind, 12, 100)
@@ -72,7 +73,7 @@ def test_filter_changes_nothing_and_rejects(eng, oracle, monkeypatch, dim, kind_
                 total[0] += seen
                 total[1] += rejected
                 assert seen <= int(want.counters[:, 0].sum()) and rejected <= seen
-    filtered = dim <= 496 or dim in (768,)              # compact rows beyond four chunks have no tile without a compile-time geometry
+    filtered = dim <= 1656                              # thin waves to 496-d, one fat filtered wave per SIMD beyond (768-d, 512-d, 1024-d)
     if not filtered:
         assert total[0] == 0
     elif kind_ == "constant":
@@ -84,11 +85,11 @@ def test_filter_changes_nothing_and_rejects(eng, oracle, monkeypatch, dim, kind_
 
 
 def test_filter_unfiltered_geometry_runs_without(eng, oracle, monkeypatch):
-    """1000-d rows: no compile-time instantiation and more than four chunks per compact row — the walk runs unfiltered."""
+    """1700-d rows: no compile-time instantiation and more than thirteen chunks per compact row — the walk runs unfiltered."""
     ida, kind = eng
     pc.use_test_build(monkeypatch)
     rng = np.random.default_rng(5)
-    n, dim, ef = S(kind, 120, 4000), 1000, S(kind, 10, 100)
+    n, dim, ef = S(kind, 100, 3000), 1700, S(kind, 10, 100)
     pts = pc.gen_points(rng, n, dim, "lowrank")
     q = pc.gen_points(rng, S(kind, 6, 200), dim, "lowrank")
     oix = oracle.Index.build(pts, oracle.default_config(ef_search=ef, ef_construction=S(kind, 12, 100)), threads=S(kind, 1, 8))
@@ -101,7 +102,8 @@ def test_filter_unfiltered_geometry_runs_without(eng, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("dim,kind_,metric", [(300, "lowrank", 0), (128, "uniform", 1), (16, "uniform", 0), (48, "outliers", 0),
-                                              (33, "offset", 1), (7, "grid", 0), (768, "lowrank", 0), (100, "nonfinite", 0)])
+                                              (33, "offset", 1), (7, "grid", 0), (768, "lowrank", 0), (100, "nonfinite", 0),
+                                              (640, "lowrank", 0)])
 def test_filter_bound_never_exceeds_the_canonical_distance(eng, oracle, dim, kind_, metric):
     """idist_filter_bound_batch: what the walk's filter compares with nearest[ef-1], for arbitrary (query, point) pairs.  The bound
     must never exceed the canonical distance of idist_distance_batch (= FloatArray::distance, py/lib.rs:378-421; the oracle's on a
