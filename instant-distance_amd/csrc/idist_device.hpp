@@ -66,7 +66,7 @@ struct FilterView {
     float slack = 0.0f;              // absolute slack of a query's own lattice error (f32 evaluation), per sqrt(dim) * magnitude
 };
 constexpr uint32_t filt_stride(uint32_t stride_floats) { return (stride_floats + 8u + 63u) & ~63u; }
-constexpr int kFiltRtChunks = 4;     // runtime-geometry rows on THIN filtered waves: a compact row of at most four 128-B chunks (dim <= 496)
+constexpr int kFiltRtChunks = 5;     // runtime-geometry rows on THIN filtered waves: a compact row of at most five 128-B chunks (dim <= 624: 512-d)
 constexpr int kFiltRtChunksFat = 13; // ... on one fat filtered wave per SIMD (longer rows, like 768-d): thirteen chunks (dim <= 1656: 512-d, 1024-d, 1536-d)
 
 // Device view of an index (plain pointers; lives in kernel arguments).
@@ -652,7 +652,8 @@ template <int NCH, bool T8, int WALK> constexpr int filt_rounds() {
     const int per_round = 4 * (T8 ? NCH - 1 : NCH) + (T8 ? 2 : 0);
     // thin waves (256 registers): all 64 rows of an expansion at 300-d / 128-d (8 x 10 / 8 x 6 registers); long rows and the
     // runtime-geometry tile keep what leaves the kernel without scratch (768-d: 2 x 26, the query's byte planes take 52 more)
-    const int budget = walk_waves(WALK) == 1 ? 256 : (NCH >= 5 ? 56 : (T8 ? 80 : 64));
+    // (fat waves: 8 x 26 at 768-d; the thirteen-chunk runtime tile keeps 2 x 52 beside its 104 registers of query bytes)
+    const int budget = walk_waves(WALK) == 1 ? (NCH >= 8 ? 128 : 256) : (NCH >= 6 ? 56 : (T8 ? 80 : 64));
     const int r = budget / per_round;
     return r > 8 ? 8 : (r < 2 ? 2 : r);
 }
