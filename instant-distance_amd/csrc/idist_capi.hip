@@ -1131,20 +1131,31 @@ idist_status filter_ensure(const idist_index* ix) {
     const uint32_t ns = std::min<uint32_t>(ix->n, 2048u), every = ix->n / ns;
     std::vector<float> smp((size_t)ns * stride);
     HIPCHK(hipMemcpy2D(smp.data(), (size_t)stride * 4, ix->d_points, (size_t)every * stride * 4, (size_t)stride * 4, ns, hipMemcpyDeviceToHost));
-    double sum = 0.0, sum2 = 0.0, mn = 0.0, mx = 0.0;
-    size_t cnt = 0;
+    // robust range: mean and sigma of the central 98 % of the sampled coordinates (a few wild values — or heavy tails — must not
+    // stretch the lattice: they are clamped, and only their own rows pay for it), sigma rescaled to the whole of a Gaussian
+    std::vector<float> vals;
+    vals.reserve((size_t)ns * ix->dim);
     for (uint32_t r = 0; r < ns; r++)
         for (uint32_t pos = 0; pos < stride; pos++) {
             if (natural_pos(pos, ix->L.nb) >= ix->dim) continue;
-            const double v = smp[(size_t)r * stride + pos];
-            if (!(std::fabs(v) <= 3.0e38)) continue;
-            if (!cnt || v < mn) mn = v;
-            if (!cnt || v > mx) mx = v;
-            sum += v; sum2 += v * v; cnt++;
+            const float v = smp[(size_t)r * stride + pos];
+            if (std::fabs(v) <= 3.0e38f) vals.push_back(v);
         }
     double lo = 0.0, hi = 1.0;
-    if (cnt) {
-        const double mean = sum / (double)cnt, sd = std::sqrt(std::max(0.0, sum2 / (double)cnt - mean * mean));
+    if (!vals.empty()) {
+        const size_t cnt = vals.size(), k0 = cnt / 100, k1 = cnt - 1 - cnt / 100;
+        std::nth_element(vals.begin(), vals.begin() + k0, vals.end());
+        const float q01 = vals[k0];
+        std::nth_element(vals.begin() + k0, vals.begin() + k1, vals.end());
+        const float q99 = vals[k1];
+        const auto mm = std::minmax_element(vals.begin(), vals.end());
+        const double mn = *mm.first, mx = *mm.second;
+        double sum = 0.0, sum2 = 0.0;
+        size_t m = 0;
+        for (const float v : vals)
+            if (v >= q01 && v <= q99) { sum += v; sum2 += (double)v * v; m++; }
+        const double mean = sum / (double)std::max<size_t>(m, 1);
+        const double sd = std::sqrt(std::max(0.0, sum2 / (double)std::max<size_t>(m, 1) - mean * mean)) / 0.93;
         lo = std::max(mn - 0.25 * sd, mean - 5.0 * sd);
         hi = std::min(mx + 0.25 * sd, mean + 5.0 * sd);
     }
