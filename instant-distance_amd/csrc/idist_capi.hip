@@ -720,8 +720,16 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         CHK(filter_ensure(ix));
         build_filter = ix->filt_state.load(std::memory_order_acquire) == 1;
     }
+    // rows beyond the thin tile whose descents run as fat waves (runtime geometries above 624-d): fat filtered descents
+    bool build_filter_fat = cfg.has_heuristic && !ext && tab16 && !a_regs256 && knobs.filter && filter_applies(ix) && !build_filter &&
+                            !has_template_geometry(ix->L) && filt_stride(ix->L.stride) > 128u * (uint32_t)kFiltRtChunks &&
+                            !(bf_env && bf_env[0] == '0');
+    if (build_filter_fat) {
+        CHK(filter_ensure(ix));
+        build_filter_fat = ix->filt_state.load(std::memory_order_acquire) == 1;
+    }
     IndexView view = ix->view();
-    if (!build_filter) view.f = FilterView{};
+    if (!build_filter && !build_filter_fat) view.f = FilterView{};
     // (one FAT filtered descent wave per SIMD, the search's layout for 768-d rows, builds 1M x 768 in 2.56 s against 2.37 s on the thin
     //  ones: the update stream needs the registers — profiles/probe_r06n_build_fat_768.jsonl)
     BuildArgs a{};
@@ -870,6 +878,8 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         auto kAo16w2 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
         /* ... and with the reject filter in front of the distance passes (thin: one f32 round in flight, query fragment from LDS) */ \
         auto kAf = build_insert_kernel<NB_, RS_, TAIL_, walk_thin_filter(2)>;                      \
+        /* long runtime-geometry rows (beyond the thin tile): their descents are fat waves anyway — the same with the filter in front */ \
+        auto kAff = build_insert_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true, false, true))>; \
         auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
@@ -879,6 +889,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         if (ext) { IDIST_LAUNCH(kX, 1, 64, smemX, sA, viewA, aA, d_ext_work, ext_cap); }           \
         IDIST_VARIANT_BUILD(NB_, RS_, TAIL_)                                                       \
         else if (tab16 && a_quad && B <= quad_B) { IDIST_LAUNCH(kAq16, std::min(B, slots), 256, smem, sA, viewA, aA); } \
+        else if (tab16 && build_filter_fat) { IDIST_LAUNCH(kAff, gridA, 64, smem, sA, viewA, aA); } \
         else if (tab16 && build_filter) { IDIST_LAUNCH(kAf, gridA, 64, smem, sA, viewA, aA); }     \
         else if (tab16 && a_regs256) { IDIST_LAUNCH(kAo16w2, gridA, 64, smem, sA, viewA, aA); }    \
         else if (tab16) { IDIST_LAUNCH(kAo16, gridA, 64, smem, sA, viewA, aA); }                   \
@@ -973,7 +984,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     ix->stats.n_updates_full = stats[7];
     ix->stats.n_filter_examined = stats[16];
     ix->stats.n_filter_rejected = stats[17];
-    ix->stats.filter_row_bytes = build_filter ? filt_stride(ix->L.stride) : 0u;
+    ix->stats.filter_row_bytes = (build_filter || build_filter_fat) ? filt_stride(ix->L.stride) : 0u;
     // the reference's own count exists only where every selection ran in the reference's order
     ix->stats.n_heur_ref = (ext || (cfg.has_heuristic && no_fast && !a2_mfma && cap == 1)) ? stats[8] : 0;
     if (prog) { prog->slot[0] = n; prog->slot[1] = 0; }

@@ -50,7 +50,7 @@ for i in range(count):
         cfg.update(filter_examined=seen, filter_rejected_share=round(rej / seen, 3) if seen else None,
                    build_filter_rejected_share=round(st.n_filter_rejected / st.n_filter_examined, 3) if st.n_filter_examined else None)
         # exact build, filtered descents forced
-        m = min(n, 2500)
+        m = min(n, 2500 if dim <= 640 else 1200)
         oex = oracle.Index.build(pts[:m], oracle.default_config(metric=metric, ef_construction=60), threads=1)
         with pc.search_variant({"IDIST_BUILD_QUAD": "0", "IDIST_BUILD_FILTER": "1"}):
             hx = ida.Hnsw.from_ordered_points(pts[:m], ida.Builder().metric(metric).ef_construction(60).max_batch(1))
