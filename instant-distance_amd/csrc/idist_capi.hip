@@ -350,6 +350,41 @@ inline bool has_template_geometry(const Layout& L) {
         if (!idist_geo_hit_) { CALL(-1, -1, -1); }                      \
     } while (0)
 
+// Which filtered kernels a row geometry can ever be given (launch_search / run_build): instantiating only those keeps the build of
+// this translation unit at three minutes.  The thin filtered walk serves compact rows of up to five chunks (128-d, 300-d, runtime
+// geometries), one fat filtered wave per SIMD the longer ones (768-d, runtime geometries); fat filtered DESCENTS exist for runtime
+// geometries only.  A launch the policy asks for and the geometry has no kernel for is an internal error, never a silent no-op.
+template <int NB> struct GeoKernels {
+    static constexpr bool thin_search = NB != 24;
+    static constexpr bool fat_filtered_search = NB == 24 || NB < 0;
+    // thin filtered descents: rows of at least 256 floats by policy — 128-d rows only under the test knob IDIST_BUILD_FILTER=1
+#if defined(IDIST_VARIANTS) || defined(IDIST_EMU) || defined(IDIST_PROBE)
+    static constexpr bool thin_descent = true;
+#else
+    static constexpr bool thin_descent = NB != 4;
+#endif
+};
+template <int NB, int RS, int TAIL, int WALK, bool ON> struct SearchLaunch {
+    static bool go(uint32_t grid, size_t smem, hipStream_t stream, const IndexView& view, const SearchArgs& a) {
+        auto kS = search_kernel<NB, RS, TAIL, WALK>;
+        IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);
+        return true;
+    }
+};
+template <int NB, int RS, int TAIL, int WALK> struct SearchLaunch<NB, RS, TAIL, WALK, false> {
+    static bool go(uint32_t, size_t, hipStream_t, const IndexView&, const SearchArgs&) { return false; }
+};
+template <int NB, int RS, int TAIL, int WALK, bool ON> struct DescentLaunch {
+    static bool go(uint32_t grid, size_t smem, hipStream_t stream, const IndexView& view, const BuildArgs& a) {
+        auto kA = build_insert_kernel<NB, RS, TAIL, WALK>;
+        IDIST_LAUNCH(kA, grid, 64, smem, stream, view, a);
+        return true;
+    }
+};
+template <int NB, int RS, int TAIL, int WALK> struct DescentLaunch<NB, RS, TAIL, WALK, false> {
+    static bool go(uint32_t, size_t, hipStream_t, const IndexView&, const BuildArgs&) { return false; }
+};
+
 idist_status index_alloc(uint32_t n, uint32_t dim, const idist_config* cfg, const uint32_t* layer_len,
                          uint32_t n_upper, int32_t device, idist_index** out) {
     if (!out) return fail(IDIST_ERR_INVALID_ARG, "out is null");
@@ -720,16 +755,10 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         CHK(filter_ensure(ix));
         build_filter = ix->filt_state.load(std::memory_order_acquire) == 1;
     }
-    // rows beyond the thin tile whose descents run as fat waves (runtime geometries above 624-d): fat filtered descents
-    bool build_filter_fat = cfg.has_heuristic && !ext && tab16 && !a_regs256 && knobs.filter && filter_applies(ix) && !build_filter &&
-                            !has_template_geometry(ix->L) && filt_stride(ix->L.stride) > 128u * (uint32_t)kFiltRtChunks &&
-                            !(bf_env && bf_env[0] == '0');
-    if (build_filter_fat) {
-        CHK(filter_ensure(ix));
-        build_filter_fat = ix->filt_state.load(std::memory_order_acquire) == 1;
-    }
+    // (fat filtered descents for runtime-geometry rows beyond the thin tile: 500k x 1024 / 1536-d 2.04 / 2.78 against 2.10 / 3.13 s —
+    //  profiles/probe_r06r_build_fat_filtered_1024.jsonl — not worth their compile time: those descents stay unfiltered)
     IndexView view = ix->view();
-    if (!build_filter && !build_filter_fat) view.f = FilterView{};
+    if (!build_filter) view.f = FilterView{};
     // (one FAT filtered descent wave per SIMD, the search's layout for 768-d rows, builds 1M x 768 in 2.56 s against 2.37 s on the thin
     //  ones: the update stream needs the registers — profiles/probe_r06n_build_fat_768.jsonl)
     BuildArgs a{};
@@ -877,9 +906,6 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         auto kAq16 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, true, true)>; \
         auto kAo16w2 = build_insert_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
         /* ... and with the reject filter in front of the distance passes (thin: one f32 round in flight, query fragment from LDS) */ \
-        auto kAf = build_insert_kernel<NB_, RS_, TAIL_, walk_thin_filter(2)>;                      \
-        /* long runtime-geometry rows (beyond the thin tile): their descents are fat waves anyway — the same with the filter in front */ \
-        auto kAff = build_insert_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true, false, true))>; \
         auto kF = build_update_fast_kernel<NB_, RS_, TAIL_>;                                       \
         auto kB = build_update_kernel<NB_, RS_, TAIL_>;                                            \
         auto kP = build_update_simple_kernel<NB_, RS_, TAIL_>;                                     \
@@ -889,8 +915,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
         if (ext) { IDIST_LAUNCH(kX, 1, 64, smemX, sA, viewA, aA, d_ext_work, ext_cap); }           \
         IDIST_VARIANT_BUILD(NB_, RS_, TAIL_)                                                       \
         else if (tab16 && a_quad && B <= quad_B) { IDIST_LAUNCH(kAq16, std::min(B, slots), 256, smem, sA, viewA, aA); } \
-        else if (tab16 && build_filter_fat) { IDIST_LAUNCH(kAff, gridA, 64, smem, sA, viewA, aA); } \
-        else if (tab16 && build_filter) { IDIST_LAUNCH(kAf, gridA, 64, smem, sA, viewA, aA); }     \
+        else if (tab16 && build_filter) { launched_a = DescentLaunch<NB_, RS_, TAIL_, walk_thin_filter(2), GeoKernels<NB_>::thin_descent>::go(gridA, smem, sA, viewA, aA); } \
         else if (tab16 && a_regs256) { IDIST_LAUNCH(kAo16w2, gridA, 64, smem, sA, viewA, aA); }    \
         else if (tab16) { IDIST_LAUNCH(kAo16, gridA, 64, smem, sA, viewA, aA); }                   \
         else { IDIST_LAUNCH(kAo, gridA, 64, smem, sA, viewA, aA); }                                \
@@ -921,7 +946,9 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
             IDIST_LAUNCH(kP, gridB, 64, (size_t)(72 * 8 + 64 * 4), sS, viewS, aS);                 \
         }                                                                                          \
     }
+            bool launched_a = true;
             IDIST_DISPATCH(ix->L, LAUNCH_BUILD);
+            if (!launched_a) { release(); return fail(IDIST_ERR_INTERNAL, "no filtered descent kernel for this row geometry"); }
 #undef LAUNCH_BUILD
             prev_start = g;
             prev_count = B;
@@ -984,7 +1011,7 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     ix->stats.n_updates_full = stats[7];
     ix->stats.n_filter_examined = stats[16];
     ix->stats.n_filter_rejected = stats[17];
-    ix->stats.filter_row_bytes = (build_filter || build_filter_fat) ? filt_stride(ix->L.stride) : 0u;
+    ix->stats.filter_row_bytes = build_filter ? filt_stride(ix->L.stride) : 0u;
     // the reference's own count exists only where every selection ran in the reference's order
     ix->stats.n_heur_ref = (ext || (cfg.has_heuristic && no_fast && !a2_mfma && cap == 1)) ? stats[8] : 0;
     if (prog) { prog->slot[0] = n; prog->slot[1] = 0; }
@@ -1256,7 +1283,9 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // Long rows (compact rows beyond four chunks: 768-d) keep ONE fat wave per SIMD with the filter: a thin wave's registers hold 16
     // of their compact rows and a quarter of an f32 row at a time — six or seven dependent round trips per expansion where the fat
     // wave makes two (C5, ef 200: 162 ms fat against 213 ms thin per 65,536 queries; C4 a tie at 78-83 ms).
-    const bool fat_filtered = filtered && !ctx->knobs.classic && filt_stride(ix->L.stride) > 128u * (uint32_t)kFiltRtChunks;
+    // (always on the quotient form of the set — the id form's cheaper probe was worth 1-2 % and another two large kernels to compile)
+    const bool fat_filtered = filtered && !ctx->knobs.classic && !ctx->knobs.tab_ids && filt_stride(ix->L.stride) > 128u * (uint32_t)kFiltRtChunks &&
+                              q16_applies(tab_fit, q16_universe_bits(ix->n, tab_fit));
     uint32_t fw = 1;
     if (filtered && !fat_filtered && !ctx->knobs.classic && !ctx->knobs.tab_ids) fw = kFilterWaves;
     if (fw > 1) {
@@ -1277,7 +1306,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // stays below the 7/8 * 2^tab_log2 ids the plain set takes, the plain set never spills and its cheaper probe wins by
     // 1-2 % (ef_search = 100: 10.25 vs 10.42 ms per 10k queries at C3, profiles/r03/probe_r03a_ef_paths_*)
     const bool ids_suffice = 53u * ef + 600u <= (7u << tab_log2) / 8u;
-    const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits) && (thin || ctx->knobs.tab_q16 || ctx->knobs.tab_log2 || !ids_suffice);
+    const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits) && (thin || fat_filtered || ctx->knobs.tab_q16 || ctx->knobs.tab_log2 || !ids_suffice);
     // Long walks (ef_search in the hundreds): an expansion costs a wave 9-10 us whatever it fetches, and it fetches fewer new rows
     // the longer the walk runs — more, thinner waves (two 256-register waves per SIMD, as many as the CU's LDS holds) keep more
     // expansions in flight than one fat wave per SIMD.
@@ -1361,6 +1390,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
 #define IDIST_VARIANT_SEARCH_ONCHIP_IDS(NB_, RS_, TAIL_)
 #define IDIST_VARIANT_SEARCH_BITMAP(NB_, RS_, TAIL_)
 #endif
+    bool launched = true;
 #define LAUNCH_SEARCH(NB_, RS_, TAIL_)                                                             \
     {                                                                                              \
         if (quad && q16) {                                                                         \
@@ -1370,17 +1400,12 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, true)>; \
             IDIST_LAUNCH(kS, grid, 256, smem, stream, view, a);                                    \
         } else if (thin) {                                                                         \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_thin_filter(2)>;                         \
-            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+            launched = SearchLaunch<NB_, RS_, TAIL_, walk_thin_filter(2), GeoKernels<NB_>::thin_search>::go(grid, smem, stream, view, a); \
         } IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_) else if (w2) {                          \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
-        } else if (on_chip && q16 && fat_filtered) {                                               \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true, false, true))>; \
-            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
         } else if (on_chip && fat_filtered) {                                                      \
-            auto kS = search_kernel<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true))>; \
-            IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+            launched = SearchLaunch<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true, false, true)), GeoKernels<NB_>::fat_filtered_search>::go(grid, smem, stream, view, a); \
         } else if (on_chip && q16) {                                                               \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, 0, false, 1, true, false, true)>; \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
@@ -1413,6 +1438,7 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
 #endif
     IDIST_DISPATCH(ix->L, LAUNCH_SEARCH);
 #undef LAUNCH_SEARCH
+    if (!launched) return fail(IDIST_ERR_INTERNAL, "no filtered search kernel for this row geometry (stride %u)", ix->L.stride);
     if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
         // nothing ran: put the queue head back where a fresh context has it
         hipMemsetAsync(ctx->d_next, 0, 4, stream);

@@ -109,7 +109,7 @@ def test_search_on_parallel_built_graph(eng, oracle):
 @pytest.mark.parametrize("n,dim,kw", [
     (1, 4, {}), (2, 4, {}), (5, 2, {"metric": 1}), (33, 3, {}), (100, 2, {"metric": 1}),
     (150, 12, {}), (120, 300, {}), (140, 8, {"ef_construction": 20}), (130, 5, {"keep_pruned": False}),
-    # 700-d: a runtime geometry beyond the thin filter tile — its single-wave descents are fat filtered waves (round 6)
+    # 700-d: a runtime geometry beyond the thin filter tile (fat, unfiltered descents; the search takes the fat filtered walk)
     (110, 700, {"kind": "lowrank"}),
     (140, 3, {"kind": "grid", "metric": 1}),
     # squared-L2 grids: exact ties d(c_i, c_j) == d(c_i, q) all over — the MFMA selection filter must send them to the
