@@ -357,6 +357,7 @@ inline bool has_template_geometry(const Layout& L) {
 template <int NB> struct GeoKernels {
     static constexpr bool thin_search = NB != 24;
     static constexpr bool fat_filtered_search = NB == 24 || NB < 0;
+    static constexpr bool fat_filtered_search_ids = NB == 24;      // (the id form of the set, cheaper to probe while a walk cannot fill it: C4)
     // thin filtered descents: rows of at least 256 floats by policy — 128-d rows only under the test knob IDIST_BUILD_FILTER=1
 #if defined(IDIST_VARIANTS) || defined(IDIST_EMU) || defined(IDIST_PROBE)
     static constexpr bool thin_descent = true;
@@ -1286,6 +1287,8 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // (always on the quotient form of the set — the id form's cheaper probe was worth 1-2 % and another two large kernels to compile)
     const bool fat_filtered = filtered && !ctx->knobs.classic && !ctx->knobs.tab_ids && filt_stride(ix->L.stride) > 128u * (uint32_t)kFiltRtChunks &&
                               q16_applies(tab_fit, q16_universe_bits(ix->n, tab_fit));
+    // ... except the 768-d instantiation while the id form of the set cannot fill up (ef_search <= ~120: C4)
+    const bool fat_ids = fat_filtered && ix->L.nb == 24 && ix->L.rs == 0 && ix->L.tail == 0;
     uint32_t fw = 1;
     if (filtered && !fat_filtered && !ctx->knobs.classic && !ctx->knobs.tab_ids) fw = kFilterWaves;
     if (fw > 1) {
@@ -1306,7 +1309,8 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
     // stays below the 7/8 * 2^tab_log2 ids the plain set takes, the plain set never spills and its cheaper probe wins by
     // 1-2 % (ef_search = 100: 10.25 vs 10.42 ms per 10k queries at C3, profiles/r03/probe_r03a_ef_paths_*)
     const bool ids_suffice = 53u * ef + 600u <= (7u << tab_log2) / 8u;
-    const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits) && (thin || fat_filtered || ctx->knobs.tab_q16 || ctx->knobs.tab_log2 || !ids_suffice);
+    const bool q16 = on_chip && !ctx->knobs.tab_ids && q16_applies(tab_log2, a.ubits) &&
+                     (thin || (fat_filtered && !(fat_ids && ids_suffice && !ctx->knobs.tab_q16 && !ctx->knobs.tab_log2)) || ctx->knobs.tab_q16 || ctx->knobs.tab_log2 || !ids_suffice);
     // Long walks (ef_search in the hundreds): an expansion costs a wave 9-10 us whatever it fetches, and it fetches fewer new rows
     // the longer the walk runs — more, thinner waves (two 256-register waves per SIMD, as many as the CU's LDS holds) keep more
     // expansions in flight than one fat wave per SIMD.
@@ -1404,6 +1408,8 @@ idist_status launch_search(const idist_index* ix, idist_search_ctx* ctx, const f
         } IDIST_VARIANT_SEARCH_ONCHIP_Q16(NB_, RS_, TAIL_) else if (w2) {                          \
             auto kS = search_kernel<NB_, RS_, TAIL_, walk_code(kWalkOverlap, (NB_) == 24 ? 1 : ((NB_) == 4 ? 6 : 3), false, 2, true, false, true)>; \
             IDIST_LAUNCH(kS, grid, 64, smem, stream, view, a);                                     \
+        } else if (on_chip && fat_filtered && !q16) {                                              \
+            launched = SearchLaunch<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true)), GeoKernels<NB_>::fat_filtered_search_ids>::go(grid, smem, stream, view, a); \
         } else if (on_chip && fat_filtered) {                                                      \
             launched = SearchLaunch<NB_, RS_, TAIL_, walk_with_filter(walk_code(kWalkOverlap, 0, false, 1, true, false, true)), GeoKernels<NB_>::fat_filtered_search>::go(grid, smem, stream, view, a); \
         } else if (on_chip && q16) {                                                               \
