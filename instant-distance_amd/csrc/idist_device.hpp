@@ -619,10 +619,10 @@ constexpr int kWalkFilterBit = 1 << 19;
 constexpr bool walk_filter(int code) { return (code & kWalkFilterBit) != 0; }
 constexpr int walk_with_filter(int code) { return code | kWalkFilterBit; }
 // Thin filtered walks (bit 20).  With the filter in front an expansion moves ~21 KB instead of ~62 KB (C3) and the walk is bound by
-// its dependent round trips, not by bytes: what helps is MORE walks per CU, each with less state — two or three waves per SIMD, the
-// f32 pass one round of 8 rows at a time (a filtered expansion keeps ~4 rows), the query fragment read from LDS, no hand-over block
-// of the four-wave walk in LDS, a smaller on-chip visited set.  (C3 ef 100, 10k queries: one wave per SIMD 7.6 ms, two 5.9 ms;
-// profiles/probe_r06c_filter_waves_c3.jsonl.)
+// its dependent round trips, not by bytes: what helps is MORE walks per CU, each with less state — two waves per SIMD, the f32 pass
+// one round of 8 rows at a time (a filtered expansion keeps ~4 rows), the query fragment read from LDS, no hand-over block of the
+// four-wave walk in LDS, a smaller on-chip visited set.  (C3 ef 100, 10k queries: one fat wave per SIMD 7.6 ms, two thin ones 4.85,
+// with all 64 compact rows of an expansion in flight 4.6; three per SIMD 4.97 — profiles/probe_r06c/d/j_*.jsonl.)
 constexpr int kWalkThinBit = 1 << 20;
 constexpr bool walk_thin(int code) { return (code & kWalkThinBit) != 0; }
 constexpr int walk_thin_filter(int waves = 2) {  // the walk code of a thin filtered walk at `waves` per SIMD: quotient set, one f32 round in flight
