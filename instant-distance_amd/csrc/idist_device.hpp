@@ -588,6 +588,9 @@ constexpr int rounds_in_flight() {
 #define IDIST_RT2_BLOCKS 6
 #endif
 constexpr bool walk_is_thin(int code) { return ((code >> 20) & 1) != 0; }   // (walk_thin, defined with the reject filter below)
+#ifndef IDIST_THIN_LONG_CHUNKED
+#define IDIST_THIN_LONG_CHUNKED 0   // blocks per group of a chunked f32 pass of thin walks on 768-d rows; 0: the row whole (see dist_rounds_walk)
+#endif
 template <int WALK> constexpr int rt_rounds() { return walk_is_thin(WALK) ? 1 : (walk_waves(WALK) == 1 ? 4 : (walk_waves(WALK) == 2 ? IDIST_RT2_ROUNDS : 1)); }
 template <int WALK> constexpr int rt_blocks() { return walk_waves(WALK) == 1 ? 8 : (walk_waves(WALK) == 2 ? IDIST_RT2_BLOCKS : 4); }
 template <int NB, int RS, int TAIL, int WALK, class Mid = NoMid>
@@ -599,8 +602,14 @@ __device__ __forceinline__ void dist_rounds_walk(const IndexView& ix, const floa
         dist_rounds_inflight<NB, RS, TAIL, RIF, !walk_q_lds(WALK), 8, Mid, walk_ea(WALK)>(ix, natural_view(q, NB), act_pid, act_dist, na, 0, mid, thr_bits);
         return;
     }
-    if constexpr ((NB < 0 || (walk_is_thin(WALK) && NB > 12)) && walk_mode(WALK) != kWalkClassic) {
-        // (thin filtered walks on long compile-time rows take the chunked tile too: a whole 768-d row is 96 registers per lane)
+    if constexpr (walk_is_thin(WALK) && NB > 12 && IDIST_THIN_LONG_CHUNKED && walk_mode(WALK) != kWalkClassic) {
+        // thin filtered walks on long compile-time rows (the 768-d build descents) with a CHUNKED f32 pass, two groups of
+        // IDIST_THIN_LONG_CHUNKED blocks on the wire — a measurement variant: the default fetches a surviving row whole (96 registers
+        // per lane, 84 B of scratch) and builds 1M x 768 in 2.01 s against 2.30 / 2.17 / 2.08 s with groups of 6 / 8 / 12 blocks
+        // (profiles/probe_r06u_thin768_whole_row.jsonl)
+        if (na <= 0) mid();
+        dist_rounds_inflight_rt<(IDIST_THIN_LONG_CHUNKED > 0 ? IDIST_THIN_LONG_CHUNKED : 1), 1>(ix, natural_view(q, (int)ix.nb), act_pid, act_dist, na, 0, mid);
+    } else if constexpr (NB < 0 && walk_mode(WALK) != kWalkClassic) {
         if (na <= 0) mid();
         dist_rounds_inflight_rt<rt_blocks<WALK>(), rt_rounds<WALK>()>(ix, natural_view(q, (int)ix.nb), act_pid, act_dist, na, 0, mid);
     } else if constexpr (RIF > 1 || (walk_rif(WALK) == 1 && NB >= 0)) {
@@ -2061,7 +2070,10 @@ __device__ __forceinline__ void search_layer(const IndexView& ix, const uint32_t
                 if constexpr (walk_filter(LAT)) { if (my_d == kAbandoned) log_d = kDlogBound | thr_bits; }
                 dlog_append(dlog, fresh ? tab_idx : -1, log_d);
             }
-            w_push_keys<push_chunks<LAT>()>(st, key, fresh);
+            // (thin walks on long compile-time rows — the 768-d build descents — merge `nearest` in eight register chunks: W of up to
+            //  512 entries in one pass, ef_construction far below; the sixteen-chunk merge's registers are the whole f32 row's)
+            constexpr int kPC = (walk_is_thin(LAT) && NB > 12) ? kPushChunks : push_chunks<LAT>();
+            w_push_keys<kPC>(st, key, fresh);
         }
         w_truncate(st);                                    // :612
         QP_MARK(5) QP_CNT(10, na)
