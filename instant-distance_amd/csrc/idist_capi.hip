@@ -358,7 +358,7 @@ template <int NB> struct GeoKernels {
     static constexpr bool thin_search = NB != 24;
     static constexpr bool fat_filtered_search = NB == 24 || NB < 0;
     static constexpr bool fat_filtered_search_ids = NB == 24;      // (the id form of the set, cheaper to probe while a walk cannot fill it: C4)
-    // thin filtered descents: rows of at least 256 floats by policy — 128-d rows only under the test knob IDIST_BUILD_FILTER=1
+    // thin filtered descents: rows of at least 192 floats by policy — 128-d rows only under the test knob IDIST_BUILD_FILTER=1
 #if defined(IDIST_VARIANTS) || defined(IDIST_EMU) || defined(IDIST_PROBE)
     static constexpr bool thin_descent = true;
 #else
@@ -744,14 +744,15 @@ idist_status run_build(idist_index* ix, idist_progress* prog, bool tie_spill) {
     // Round 6: the descents of concurrent steps run with the reject filter in front of their distance passes (§4.5) — the compact
     // copy of the rows is made now (every row is in place before the first insertion), the log takes bound-form entries for the
     // candidates the filter turned down, step B resolves them (dlog_resolve).  IDIST_BUILD_FILTER=0 (test knob): without.
-    // Rows of at least 256 floats: C3 1.20 -> 1.03 s, 1M x 768 2.82 -> 2.35 s, 1M x 384 1.71 -> 1.29 s; 128-d rows lose (a 192-B compact
+    // Rows of at least 192 floats: C3 1.20 -> 1.03 s, 1M x 768 2.82 -> 2.01 s, 1M x 384 1.71 -> 1.29 s, 1M x 200 1.22 -> 1.12 s
+    // (probe_r06v_build_filter_128_recheck.jsonl); 128-d rows lose (a 192-B compact
     // row saves little of a 512-B one and their fat unfiltered descents are faster: 1M x 128 0.70 -> 0.85 s, C2 0.107 -> 0.118 s) and
     // keep the unfiltered descents (profiles/probe_r06g_build_filter_c3.jsonl, probe_r06h_build_filter_dims.jsonl; same graphs).
     // IDIST_BUILD_FILTER=1 (test knob) forces it for every geometry the filter applies to.
     const char* bf_env = test_env("IDIST_BUILD_FILTER");
     bool build_filter = cfg.has_heuristic && !ext && tab16 && knobs.filter && filter_applies(ix) &&
                         (has_template_geometry(ix->L) || filt_stride(ix->L.stride) <= 128u * (uint32_t)kFiltRtChunks) &&   // (the thin tile)
-                        (bf_env ? bf_env[0] != '0' : ix->L.stride >= 256u);
+                        (bf_env ? bf_env[0] != '0' : ix->L.stride >= 192u);
     if (build_filter) {
         CHK(filter_ensure(ix));
         build_filter = ix->filt_state.load(std::memory_order_acquire) == 1;

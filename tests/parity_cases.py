@@ -39,7 +39,7 @@ SEARCH_VARIANTS = (("default (narrow batches: four waves per query; wide ones by
 # (the third field: the variant runs every selection in the reference's own order, so its count of distance calls inside
 #  select_heuristic / add_neighbor_heuristic must equal the oracle's n_heur)
 BUILD_VARIANTS = (("on-chip (narrow steps: four waves per insertion)", {}),
-                  ("on-chip, one wave per insertion also in narrow steps (descents with the reject filter where the policy has it: rows >= 256 floats)", {"IDIST_BUILD_QUAD": "0"}),
+                  ("on-chip, one wave per insertion also in narrow steps (descents with the reject filter where the policy has it: rows >= 192 floats)", {"IDIST_BUILD_QUAD": "0"}),
                   ("on-chip, one wave per insertion, descents WITH the reject filter at every row length", {"IDIST_BUILD_QUAD": "0", "IDIST_BUILD_FILTER": "1"}),
                   ("on-chip, one wave per insertion, descents WITHOUT the reject filter", {"IDIST_BUILD_QUAD": "0", "IDIST_BUILD_FILTER": "0"}),
                   ("on-chip, 512-register descent waves", {"IDIST_BUILD_QUAD": "0", "IDIST_BUILD_A_REGS": "512"}),
